@@ -1,0 +1,75 @@
+"""ctypes mirror of ``include/ftl.h`` (the C-ABI of the HIP library).
+
+Field order and types must match the header exactly; ``tests/test_abi.py`` checks the struct sizes
+against ``ftl_sizeof_*`` exported by the library."""
+import ctypes as C
+
+FTL_ABI_VERSION = 1
+FTL_MAX_BEARS = 4
+FTL_MAX_LASERS = 4
+FTL_OBS_NUM = 10
+
+FTL_OK = 0
+FTL_E_INVALID, FTL_E_UNSUPPORTED, FTL_E_DEVICE, FTL_E_STATE = -1, -2, -3, -4
+
+MISSION = ("in_progress", "fail", "success", "finished_by_time")          # ENV:951-955, 963, 1083, 1130
+AGENT = ("moving", "crash", "low_reward", "too_far_from_leader", "finished")
+LEADER = ("moving", "crash", "finished")
+
+FTL_ERR_TRAJ_OVERFLOW, FTL_ERR_CORR_OVERFLOW, FTL_ERR_EMPTY_CORRIDOR, FTL_ERR_TRACKER_SEED = 1, 2, 4, 8
+FTL_STEP_AUTO_RESET = 1
+
+# env_int indices
+(EI_SCEN, EI_TARGET_ID, EI_LEADER_FINISHED, EI_DONE, EI_CRASH, EI_IN_BOX, EI_ON_TRACE, EI_TOO_CLOSE,
+ EI_STEP_COUNT, EI_FINISH_TIMER, EI_TRAJ_LEN, EI_TRK_COUNTER, EI_CORR_LO, EI_CORR_HI, EI_SEED_END,
+ EI_SNAP_COUNT, EI_DYN_INDEX0, EI_DYN_INDEX1, EI_DYN_INDEX2, EI_DYN_INDEX3, EI_ERROR, EI_EPISODES,
+ EI_GREEN_COUNT, EI_SPARE, EI_COUNT) = range(25)
+ED_ACC_PENALTY, ED_OVERALL_REWARD, ED_SPARE0, ED_SPARE1, ED_BEAR_POINTS = range(5)
+ED_COUNT = ED_BEAR_POINTS + 2 * FTL_MAX_BEARS
+RD_DIRECTION, RD_SPEED, RD_ROT_SPEED, RD_DES_SPEED, RD_DES_ROT_SPEED, RD_COUNT = range(6)
+RI_X, RI_Y, RI_W, RI_H, RI_ROT_DIR, RI_DES_ROT_DIR, RI_SPARE0, RI_SPARE1, RI_COUNT = range(9)
+
+
+class RobotParams(C.Structure):
+    _fields_ = [("min_speed", C.c_double), ("max_speed", C.c_double), ("max_rotation_speed", C.c_double),
+                ("max_speed_change", C.c_double), ("max_rotation_speed_change", C.c_double),
+                ("img_w", C.c_int32), ("img_h", C.c_int32), ("_pad", C.c_int32 * 2)]
+
+
+class LaserCfg(C.Structure):
+    _fields_ = [("count", C.c_int32), ("react_corridor", C.c_int32), ("react_green", C.c_int32),
+                ("react_obstacles", C.c_int32), ("history", C.c_int32), ("after_tracker", C.c_int32),
+                ("out_offset", C.c_int32), ("_pad", C.c_int32), ("length", C.c_double), ("angle_offset", C.c_double)]
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("frames_per_step", C.c_int32), ("max_steps", C.c_int32), ("warm_start", C.c_int32),
+                ("trajectory_saving_period", C.c_int32), ("n_static", C.c_int32), ("n_bears", C.c_int32),
+                ("move_bear_v4", C.c_int32), ("ignore_follower_collisions", C.c_int32),
+                ("aggregate_reward", C.c_int32), ("has_low_reward", C.c_int32),
+                ("has_max_distance_coef", C.c_int32), ("has_tracker", C.c_int32),
+                ("tracker_saving_period", C.c_int32), ("tracker_start_behind", C.c_int32),
+                ("n_lasers", C.c_int32), ("traj_cap", C.c_int32), ("corr_cap", C.c_int32),
+                ("route_cap", C.c_int32), ("init_traj_cap", C.c_int32), ("_pad0", C.c_int32 * 2),
+                ("low_reward", C.c_double), ("max_distance_coef", C.c_double),
+                ("min_distance", C.c_double), ("max_distance", C.c_double), ("max_dev", C.c_double),
+                ("leader_pos_epsilon", C.c_double), ("corridor_length", C.c_double),
+                ("corridor_width", C.c_double),
+                ("reward_in_box", C.c_double), ("reward_on_track", C.c_double), ("reward_in_dev", C.c_double),
+                ("not_on_track_penalty", C.c_double), ("crash_penalty", C.c_double),
+                ("too_close_penalty", C.c_double), ("leader_movement_reward", C.c_double),
+                ("leader", RobotParams), ("follower", RobotParams), ("bear", RobotParams),
+                ("lasers", LaserCfg * FTL_MAX_LASERS)]
+
+
+class Scenarios(C.Structure):
+    _fields_ = [("n_scenarios", C.c_int32), ("_pad", C.c_int32),
+                ("static_rects", C.c_void_p), ("robot_pos", C.c_void_p), ("robot_dir", C.c_void_p),
+                ("robot_rect", C.c_void_p), ("route", C.c_void_p), ("route_len", C.c_void_p),
+                ("init_traj", C.c_void_p), ("init_traj_len", C.c_void_p)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("obs_num", C.c_void_p), ("lasers", C.c_void_p), ("target", C.c_void_p),
+                ("reward", C.c_void_p), ("done", C.c_void_p), ("status", C.c_void_p)]

@@ -1,0 +1,293 @@
+"""Host-side mirror of ``Game.__init__`` (reference ``follow_the_leader_continuous_env.py:45-417``):
+same keyword arguments, defaults, unit conversion (metres -> px, per-second -> per-frame with
+``AVG_FRAMES_PER_SECOND = 100``, ENV:38, 330-357) and error behaviour, producing the frozen
+``ftl_config`` the C-ABI takes.  Nothing here computes on the hot path."""
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from warnings import warn
+
+from . import abi
+
+AVG_FRAMES_PER_SECOND = 100  # ENV:38
+
+# Reward dataclass defaults (utils/reward_constructor.py:4-16); Game overrides leader_movement_reward=0 (ENV:279)
+REWARD_DEFAULTS = dict(reward_in_box=1.0, reward_on_track=0.1, reward_in_dev=0.5, leader_movement_reward=1.0,
+                       crash_penalty=-10.0, not_on_track_penalty=-1.0, too_close_penalty=-5.0,
+                       leader_stop_penalty=-1.0)
+
+# SENSOR_CLASSNAME_TO_CLASS (utils/sensors.py:1291-1307): the classes on the accelerated path.
+SUPPORTED_SENSOR_CLASSES = ("LeaderPositionsTracker_v2", "LeaderCorridor_Prev_lasers_v2")
+KNOWN_SENSOR_CLASSES = ("LaserSensor", "LeaderPositionsTracker", "LeaderPositionsTracker_v2",
+                        "LeaderTrackDetector_vector", "LeaderTrackDetector_radar", "LeaderCorridor_lasers",
+                        "GreenBoxBorderSensor", "LeaderCorridor_lasers_v2", "LeaderObstacles_lasers",
+                        "Leader_Dyn_Obstacles_lasers", "FollowerInfo", "LaserPrevSensor",
+                        "LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_Prev_lasers_v3",
+                        "LeaderCorridor_lasers_compas")
+
+
+@dataclass
+class LaserSpec:
+    name: str
+    count: int
+    length: float
+    react_corridor: bool
+    react_green: bool
+    react_obstacles: int          # 0 False, 1 True/"all", 2 "static", 3 "dynamic"
+    history: int
+    angle_offset: float
+    after_tracker: bool
+    out_offset: int = 0
+
+
+@dataclass
+class GameConfig:
+    """Parsed constructor arguments + the ctypes struct."""
+    kwargs: dict
+    c: abi.Config
+    lasers: list = field(default_factory=list)
+    tracker_name: str = None
+    sensor_order: list = field(default_factory=list)
+    discrete_action_space: bool = False
+    constant_follower_speed: bool = False
+    discrete_rotation_speed_to_value: dict = None
+    pixels_to_meter: float = 50
+    action_low: tuple = None
+    action_high: tuple = None
+
+    @property
+    def n_robots(self):
+        return 2 + self.c.n_bears
+
+    @property
+    def lasers_len(self):
+        return sum(l.history * l.count for l in self.lasers)
+
+
+def _react_code(v):
+    if v is False or v is None:
+        return 0
+    if v is True or v == "all":
+        return 1
+    if v == "static":
+        return 2
+    if v == "dynamic":
+        return 3
+    # the reference builds a ValueError here without raising it and then fails on an unbound name (SEN:661-664)
+    raise ValueError("You need to specify which obstacles the sensor should respond to. Set react_to_obstacles "
+                     "equal to one of the values: True, 'all', 'dynamic', 'static'")
+
+
+def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_step=10,
+                random_frames_per_step=None, caption=None, trajectory=None, leader_pos_epsilon=25,
+                show_leader_path_flag=True, show_leader_trajectory_flag=True, show_rectangles_flag=True,
+                show_box_flag=True, show_objects_flag=True, show_sensors_flag=True,
+                simulation_time_limit=None, reward_config=None, pixels_to_meter=50,
+                min_distance=1, max_distance=4, max_dev=1, warm_start=500, manual_control=False,
+                manual_control_input="keyboard", max_steps=5000, aggregate_reward=False,
+                add_obstacles=True, add_bear=True, bear_number=3, multi_random_bears=False,
+                move_bear_v4=True, obstacle_number=35, bear_behind=False, step_grid=10,
+                early_stopping=None, follower_sensors=None, leader_speed_regime=None,
+                leader_acceleration_regime=None, discrete_action_space=False,
+                constant_follower_speed=False, path_finding_algorythm="dstar",
+                multiple_end_points=False, negative_speed=False, follower_max_speed=0.5,
+                leader_max_speed=0.5, follower_max_rotation_speed=57.296,
+                leader_max_rotation_speed=57.296, follower_acceleration=0.005,
+                leader_acceleration=0.005, bear_max_speed=1.1, follower_size=(0.5, 0.35),
+                leader_size=(0.38, 0.52), bear_size=(0.5, 0.5), bridge_size=(80, 40),
+                return_render_matrix=True, ignore_follower_collisions=False,
+                path_finding_iterations=15000, leader_margin=1.5,
+                # capacities of the fixed per-env slots of the batched state (no reference equivalent)
+                traj_cap=None, corr_cap=None, route_cap=128, init_traj_cap=None, n_static=None,
+                **kwargs):
+    """Same signature and defaults as ``Game.__init__`` (ENV:45-105); unknown kwargs are swallowed like the
+    reference's ``**kwargs`` (ENV:104)."""
+    early_stopping = {} if early_stopping is None else early_stopping
+    follower_sensors = {} if follower_sensors is None else follower_sensors
+    all_kwargs = dict(locals())
+    all_kwargs.pop("kwargs")
+
+    # ---- error behaviour of the reference constructor -------------------------------------------
+    if multiple_end_points and path_finding_algorythm != "dstar":  # ENV:239-243
+        raise NotImplementedError("Only dstar pathfinding function supports multiple end points. "
+                                  "multiple_end_points must be False or diggerent path_finding_algorythm "
+                                  "must be chosen")
+    if path_finding_algorythm not in ["astar", "dstar"]:  # ENV:423-425
+        raise ValueError("path_finding_algorythm {} not in list:{}".format(path_finding_algorythm, ["astar", "dstar"]))
+    if add_bear and bear_number <= 0:  # ENV:426-427
+        raise ValueError("Add bear is true, but number of bears is not greater then 0")
+    if random_frames_per_step is not None and frames_per_step is not None:
+        assert len(random_frames_per_step) == 2, \
+            "random frames per step должен быть задан в виде границ для генерации случайных значений. " \
+            "Задано: {}".format(random_frames_per_step)  # ENV:402-404
+
+    # ---- features of the reference that are outside the accelerated hot path ----------------------
+    if manual_control:
+        raise NotImplementedError("manual_control (pygame event loop, ENV:913-915) is not part of the batched step path")
+    if random_frames_per_step is not None:
+        raise NotImplementedError("random_frames_per_step draws np.random inside step (ENV:939-940); not supported yet")
+    if type(leader_speed_regime) in (dict, OrderedDict) or type(leader_acceleration_regime) in (dict, OrderedDict):
+        raise NotImplementedError("leader_speed_regime / leader_acceleration_regime (ENV:1143-1174, global `random` "
+                                  "per frame) are scheduled for a later round (SURVEY.md config E)")
+    if leader_speed_regime is not None:
+        warn("leader_speed_regime должен быть dict или OrderedDict, получено: {}, будет проигнорировано".format(
+            type(leader_speed_regime)))  # ENV:387-389
+    if leader_acceleration_regime is not None:
+        warn("leader_acceleration_regime должен быть dict, получено: {}, будет проигнорировано".format(
+            type(leader_acceleration_regime)))
+    if simulation_time_limit is not None:
+        raise NotImplementedError("simulation_time_limit depends on the wall clock (ENV:1119-1123)")
+    if add_bear and bear_number > abi.FTL_MAX_BEARS:
+        raise NotImplementedError("bears with index >= 4 draw from `random` inside step (ENV:750-754)")
+
+    def to_px(m):  # ENV:1942-1943
+        return m * pixels_to_meter
+
+    c = abi.Config()
+    c.abi_version = abi.FTL_ABI_VERSION
+    c.width, c.height = int(game_width), int(game_height)
+    c.frames_per_step = int(frames_per_step)
+    c.max_steps = int(max_steps)
+    c.warm_start = int(warm_start)
+    c.trajectory_saving_period = 5  # ENV:262
+    n_obst = obstacle_number if add_obstacles else 0  # ENV:322-323
+    c.n_static = (n_obst + 2 if add_obstacles else 0) if n_static is None else int(n_static)  # two bridge walls + rocks
+    c.n_bears = int(bear_number) if add_bear else 0
+    c.move_bear_v4 = int(bool(move_bear_v4))
+    c.ignore_follower_collisions = int(bool(ignore_follower_collisions))
+    c.aggregate_reward = int(bool(aggregate_reward))
+    c.has_low_reward = int("low_reward" in early_stopping)
+    c.low_reward = float(early_stopping.get("low_reward", 0.0))
+    c.has_max_distance_coef = int("max_distance_coef" in early_stopping)
+    c.max_distance_coef = float(early_stopping.get("max_distance_coef", 0.0))
+    c.min_distance = to_px(min_distance)
+    c.max_distance = to_px(max_distance)
+    c.max_dev = to_px(max_dev)
+    c.leader_pos_epsilon = leader_pos_epsilon
+
+    rw = dict(REWARD_DEFAULTS)
+    if reward_config:
+        import json
+        with open(reward_config, "r") as fh:  # Reward.from_json, reward_constructor.py:21-26
+            d = json.load(fh)
+        d.pop("name", None)
+        rw.update(d)
+    else:
+        rw["leader_movement_reward"] = 0  # ENV:279
+    for k in ("reward_in_box", "reward_on_track", "reward_in_dev", "not_on_track_penalty", "crash_penalty",
+              "too_close_penalty", "leader_movement_reward"):
+        setattr(c, k, float(rw[k]))
+
+    # ---- robots (ENV:330-357, 556-566, 578-589, 704-714) -----------------------------------------
+    def fill(p, min_speed, max_speed, max_rot, acc, w, h):
+        p.min_speed, p.max_speed = float(min_speed), float(max_speed)
+        p.max_rotation_speed = float(max_rot)
+        p.max_speed_change = float(acc)
+        p.max_rotation_speed_change = 20 / 100
+        p.img_w, p.img_h = int(w), int(h)  # pygame.transform.scale truncates (CLS:42)
+
+    f_max = to_px(follower_max_speed) / AVG_FRAMES_PER_SECOND
+    f_min = -(to_px(follower_max_speed) / AVG_FRAMES_PER_SECOND) if negative_speed else 0
+    fill(c.follower, f_min, f_max, follower_max_rotation_speed / AVG_FRAMES_PER_SECOND,
+         to_px(follower_acceleration) / AVG_FRAMES_PER_SECOND,
+         to_px(follower_size[1]), to_px(follower_size[0]))            # height=size[0], width=size[1] (ENV:333-334)
+    l_max = to_px(leader_max_speed) / AVG_FRAMES_PER_SECOND
+    fill(c.leader, 0, l_max, leader_max_rotation_speed / AVG_FRAMES_PER_SECOND,
+         to_px(leader_acceleration) / AVG_FRAMES_PER_SECOND,
+         to_px(leader_size[0]), to_px(leader_size[1]))                # width=size[0], height=size[1] (ENV:352-353)
+    fill(c.bear, 0, bear_max_speed * l_max, leader_max_rotation_speed / AVG_FRAMES_PER_SECOND,
+         to_px(0.005), to_px(bear_size[1]), to_px(bear_size[0]))      # ENV:706-711
+
+    # ---- sensors (CLS:239-253 registry protocol, dict order matters: CLS:269-286) ------------------
+    lasers, tracker_name, order = [], None, []
+    seen_tracker = False
+    for name, spec in follower_sensors.items():
+        spec = dict(spec)
+        cls = spec.pop("sensor_class", None)
+        if cls is None:
+            if name in KNOWN_SENSOR_CLASSES:
+                cls = name
+            else:
+                raise ValueError(f"Sensor class is undefined: {name}")  # CLS:249
+        if cls not in KNOWN_SENSOR_CLASSES:
+            raise KeyError(cls)  # SENSOR_CLASSNAME_TO_CLASS[...] lookup, CLS:245
+        if cls not in SUPPORTED_SENSOR_CLASSES:
+            raise NotImplementedError(f"sensor class {cls} is outside the accelerated hot path "
+                                      f"(supported: {SUPPORTED_SENSOR_CLASSES})")
+        order.append((name, cls))
+        if cls == "LeaderPositionsTracker_v2":
+            if name != "LeaderPositionsTracker_v2":
+                # use_sensors looks the tracker up by this literal key (CLS:263)
+                raise NotImplementedError("the tracker must be registered under the key 'LeaderPositionsTracker_v2' "
+                                          "(CLS:263 looks it up by name)")
+            if spec.get("eat_close_points", True):
+                # inherited default eat_close_points=True is never applied by the v2 scan (SEN:243-327)
+                pass
+            if not spec.get("generate_corridor", True):
+                raise NotImplementedError("generate_corridor=False leaves `leader_corridor` unbound for the ray sensors")
+            c.has_tracker = 1
+            c.tracker_saving_period = int(spec.get("saving_period", 5))
+            c.tracker_start_behind = int(bool(spec.get("start_corridor_behind_follower", False)))
+            c.corridor_length = float(spec["corridor_length"])   # required keyword-only args (SEN:238)
+            c.corridor_width = float(spec["corridor_width"])
+            tracker_name = name
+            seen_tracker = True
+        else:
+            n = int(spec.get("lasers_count", 12))
+            if n not in (12, 24, 20, 36) and not spec.get("_allow_any_lasers_count", False):
+                raise ValueError("Invalid number of laser beams, should be 12,24,20 or 36")  # SEN:761-762
+            hist = spec.get("max_prev_obs", 0)
+            assert hist > 0  # SEN:876
+            if spec.get("pad_sectors", True):
+                raise NotImplementedError("pad_sectors=True output layout (SEN:932-953) is scheduled next; "
+                                          "pass pad_sectors=False")
+            lasers.append(LaserSpec(name=name, count=n, length=float(spec.get("laser_length", 100)),
+                                    react_corridor=bool(spec.get("react_to_safe_corridor", True)),
+                                    react_green=bool(spec.get("react_to_green_zone", False)),
+                                    react_obstacles=_react_code(spec.get("react_to_obstacles", False)),
+                                    history=int(hist),
+                                    angle_offset=float(spec.get("first_laser_angle_offset", -45)),
+                                    after_tracker=seen_tracker))
+    if lasers and not c.has_tracker:
+        raise NotImplementedError("ray sensors need LeaderPositionsTracker_v2 (reference: NameError on "
+                                  "`leader_corridor`, CLS:280)")
+    if len(lasers) > abi.FTL_MAX_LASERS:
+        raise NotImplementedError(f"at most {abi.FTL_MAX_LASERS} ray sensors")
+    c.n_lasers = len(lasers)
+    off = 0
+    for k, l in enumerate(lasers):
+        l.out_offset = off
+        lc = c.lasers[k]
+        lc.count, lc.length, lc.history = l.count, l.length, l.history
+        lc.react_corridor, lc.react_green, lc.react_obstacles = int(l.react_corridor), int(l.react_green), l.react_obstacles
+        lc.angle_offset, lc.after_tracker, lc.out_offset = l.angle_offset, int(l.after_tracker), off
+        off += l.history * l.count
+
+    # ---- capacities ---------------------------------------------------------------------------------
+    # leader_factual_trajectory: initial int(dist/(5*v)) points, dist < 0.9*max_distance, then one point per
+    # trajectory_saving_period frames up to max_steps (+ the frames of the step that crosses it).
+    init_pts = int(0.9 * c.max_distance / (5 * l_max)) + 2
+    c.init_traj_cap = int(init_traj_cap) if init_traj_cap else ((init_pts + 7) // 8) * 8
+    need = c.init_traj_cap + (c.max_steps + 2 * c.frames_per_step) // 5 + 8
+    c.traj_cap = int(traj_cap) if traj_cap else ((need + 63) // 64) * 64
+    if corr_cap:
+        c.corr_cap = int(corr_cap)
+    elif c.has_tracker:
+        # points are >= tracker_saving_period/2 steps of leader motion apart once the leader runs at full speed;
+        # seeded points are period*5*v apart.  4x head-room, overflow is detected (FTL_ERR_CORR_OVERFLOW).
+        seed_gap = c.tracker_saving_period * 5 * l_max
+        c.corr_cap = max(32, ((int(4 * c.corridor_length / max(seed_gap, 1e-9)) + 15) // 16) * 16)
+    else:
+        c.corr_cap = 16
+    c.route_cap = int(route_cap)
+
+    cfg = GameConfig(kwargs=all_kwargs, c=c, lasers=lasers, tracker_name=tracker_name, sensor_order=order,
+                     discrete_action_space=bool(discrete_action_space),
+                     constant_follower_speed=bool(constant_follower_speed), pixels_to_meter=pixels_to_meter)
+    max_rot = c.follower.max_rotation_speed
+    if discrete_action_space:  # ENV:360-367
+        cfg.discrete_rotation_speed_to_value = {0: -max_rot, 1: -max_rot / 2, 2: 0, 3: max_rot / 2, 4: max_rot}
+    elif constant_follower_speed:  # ENV:368-372
+        cfg.action_low, cfg.action_high = (-max_rot,), (max_rot,)
+    else:  # ENV:373-378
+        cfg.action_low, cfg.action_high = (c.follower.min_speed, -max_rot), (c.follower.max_speed, max_rot)
+    return cfg

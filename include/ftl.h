@@ -1,0 +1,192 @@
+/*
+ * ftl.h -- C-ABI of the MI355X-native batched `Game.step()` for the 2-D
+ * continuous_grid_arctic follow-the-leader environment.
+ *
+ * The reference has no FFI layer: the path sits behind the gym API of
+ * `class Game(gym.Env)` (reference src/continuous_grid_arctic/
+ * follow_the_leader_continuous_env.py, "ENV" below) plus the sensor plugin
+ * registry (utils/sensors.py "SEN", utils/classes.py "CLS").  The entry points
+ * below are what a ctypes binding inside the reference's `Game` would call in
+ * place of its Python hot loop; each one cites the reference interface it
+ * replaces.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every function
+ * returns 0 on success or a negative FTL_E_* code and stores a message
+ * retrievable with ftl_last_error(); a handle is bound to one (process,
+ * device, stream-at-call-time) and is not thread-safe -- the same contract as
+ * the reference (one env object per process, Python exceptions instead of
+ * codes).  All buffer arguments of ftl_reset/ftl_step are DEVICE pointers
+ * owned by the caller (PyTorch-ROCm tensors); the library only borrows them
+ * for the duration of the call.
+ */
+#ifndef FTL_H
+#define FTL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTL_ABI_VERSION 1
+#define FTL_MAX_BEARS 4   /* bears with index >= 4 draw from `random` inside step (ENV:750-754): unsupported */
+#define FTL_MAX_LASERS 4
+#define FTL_OBS_NUM 10    /* numerical_features, ENV:1793-1802 */
+
+/* error codes */
+#define FTL_OK 0
+#define FTL_E_INVALID (-1)   /* bad argument / config rejected (reference: ValueError, ENV:419-427, SEN:761-762) */
+#define FTL_E_UNSUPPORTED (-2) /* reference feature outside the hot-path scope (NotImplementedError) */
+#define FTL_E_DEVICE (-3)    /* HIP runtime error */
+#define FTL_E_STATE (-4)     /* call order: state not bound / scenarios not loaded */
+
+/* status codes written to `status[n][3]` = info dict of ENV:951-955 */
+enum { FTL_MISSION_IN_PROGRESS = 0, FTL_MISSION_FAIL = 1, FTL_MISSION_SUCCESS = 2, FTL_MISSION_FINISHED_BY_TIME = 3 };
+enum { FTL_AGENT_MOVING = 0, FTL_AGENT_CRASH = 1, FTL_AGENT_LOW_REWARD = 2, FTL_AGENT_TOO_FAR = 3, FTL_AGENT_FINISHED = 4 };
+enum { FTL_LEADER_MOVING = 0, FTL_LEADER_CRASH = 1, FTL_LEADER_FINISHED = 2 };
+
+/* per-env error bits (env_int[FTL_EI_ERROR]); a reference run would have raised here */
+#define FTL_ERR_TRAJ_OVERFLOW 1u      /* leader_factual_trajectory longer than traj_cap */
+#define FTL_ERR_CORR_OVERFLOW 2u      /* tracker history longer than corr_cap */
+#define FTL_ERR_EMPTY_CORRIDOR 4u     /* SEN:893/962: scan with len(corridor) <= 1 (reference: UnboundLocalError) */
+#define FTL_ERR_TRACKER_SEED 8u       /* SEN:264-297: fewer than 2 seed points / popleft on empty corridor */
+
+/* robot kinematic limits, px/frame and deg/frame (ENV:330-357, 556-566, 704-714; CLS:59-105) */
+typedef struct ftl_robot_params {
+    double min_speed, max_speed;
+    double max_rotation_speed;
+    double max_speed_change;          /* "acceleration" */
+    double max_rotation_speed_change; /* 20/100 everywhere in the reference */
+    int32_t img_w, img_h;             /* size of the scaled sprite = un-rotated hitbox (CLS:42) */
+    int32_t _pad[2];
+} ftl_robot_params;
+
+/* one LeaderCorridor_Prev_lasers_v2 instance (SEN:742-769, 873-881) */
+typedef struct ftl_laser_cfg {
+    int32_t count;            /* lasers_count */
+    int32_t react_corridor;   /* react_to_safe_corridor */
+    int32_t react_green;      /* react_to_green_zone */
+    int32_t react_obstacles;  /* 0 False, 1 True/"all", 2 "static", 3 "dynamic" (SEN:651-660) */
+    int32_t history;          /* max_prev_obs (rows of the output) */
+    int32_t after_tracker;    /* 1: scanned after the tracker's 2nd scan of the step (dict order, CLS:269-286) */
+    int32_t out_offset;       /* filled by the library: offset of this sensor's [history][count] block in `lasers` */
+    int32_t _pad;
+    double length;            /* laser_length, px */
+    double angle_offset;      /* first_laser_angle_offset, deg */
+} ftl_laser_cfg;
+
+/* Game(**kwargs) after unit conversion (ENV:45-105, 283-357) */
+typedef struct ftl_config {
+    int32_t abi_version;
+    int32_t width, height;               /* game_width, game_height */
+    int32_t frames_per_step;
+    int32_t max_steps;                   /* in frames (ENV:1127-1134) */
+    int32_t warm_start;                  /* in frames */
+    int32_t trajectory_saving_period;    /* 5, ENV:262 */
+    int32_t n_static;                    /* walls + rocks */
+    int32_t n_bears;
+    int32_t move_bear_v4;
+    int32_t ignore_follower_collisions;
+    int32_t aggregate_reward;
+    int32_t has_low_reward, has_max_distance_coef; /* early_stopping keys, ENV:1088-1107 */
+    int32_t has_tracker;                 /* LeaderPositionsTracker_v2 present */
+    int32_t tracker_saving_period;
+    int32_t tracker_start_behind;        /* start_corridor_behind_follower */
+    int32_t n_lasers;
+    int32_t traj_cap;                    /* capacity of leader_factual_trajectory per env (points) */
+    int32_t corr_cap;                    /* capacity of tracker history / corridor ring per env */
+    int32_t route_cap;                   /* capacity of the planned route per scenario (waypoints) */
+    int32_t init_traj_cap;               /* capacity of the initial trajectory per scenario */
+    int32_t _pad0[2];
+    double low_reward, max_distance_coef;
+    double min_distance, max_distance, max_dev; /* px */
+    double leader_pos_epsilon;
+    double corridor_length, corridor_width;
+    /* Reward dataclass, reward_constructor.py:4-16 with leader_movement_reward=0 (ENV:279) */
+    double reward_in_box, reward_on_track, reward_in_dev, not_on_track_penalty;
+    double crash_penalty, too_close_penalty, leader_movement_reward;
+    ftl_robot_params leader, follower, bear;
+    ftl_laser_cfg lasers[FTL_MAX_LASERS];
+} ftl_config;
+
+/* Scenario pool = output of the reference's reset() (ENV:434-543) for P episodes, device arrays.
+ * Robots are ordered leader, follower, bear0.. (R = 2 + n_bears). */
+typedef struct ftl_scenarios {
+    int32_t n_scenarios;
+    int32_t _pad;
+    const int32_t* static_rects;   /* [P][n_static][4]  x,y,w,h  (integer pygame.Rect) */
+    const float*   robot_pos;      /* [P][R][2]  f32 positions (CLS:47) */
+    const double*  robot_dir;      /* [P][R]     start directions, deg */
+    const int32_t* robot_rect;     /* [P][R][4] */
+    const double*  route;          /* [P][route_cap][2]  planned route waypoints (ENV:1547-1550) */
+    const int32_t* route_len;      /* [P] */
+    const float*   init_traj;      /* [P][init_traj_cap][2]  initial leader_factual_trajectory (ENV:533-539) */
+    const int32_t* init_traj_len;  /* [P] */
+} ftl_scenarios;
+
+/* step()/reset() outputs = (obs, reward, done, info) of ENV:945 for n envs, device arrays */
+typedef struct ftl_outputs {
+    float*   obs_num;    /* [n][10]            numerical_features (ENV:1793-1802) */
+    float*   lasers;     /* [n][lasers_len]    per sensor k a [history_k][count_k] block at lasers[k].out_offset */
+    double*  target;     /* [n][2]             leader_target_point (ENV:1803-1806) */
+    double*  reward;     /* [n]                last-frame reward (ENV:935-936, 1136-1141) */
+    uint8_t* done;       /* [n] */
+    uint8_t* status;     /* [n][3]             mission / agent / leader status codes */
+} ftl_outputs;
+
+typedef struct ftl_handle ftl_handle;
+
+/* flags of ftl_step */
+#define FTL_STEP_AUTO_RESET 1u  /* envs that finish are re-initialised from scenario (scen_idx+n_envs) % P inside the
+                                   same launch; outputs keep the terminal reward/done/status, obs are the new episode's */
+
+/* Game.__init__ (ENV:45-417): validate + freeze the config. device < 0 is rejected (there is no CPU path). */
+int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle** out);
+void ftl_destroy(ftl_handle* h);
+
+/* number of f32 elements per env in ftl_outputs.lasers */
+int32_t ftl_lasers_len(const ftl_handle* h);
+/* copy of the frozen config (out_offset of every laser filled in) */
+int ftl_get_config(const ftl_handle* h, ftl_config* out);
+
+/* Per-env mutable state lives in ONE caller-owned device buffer (a torch uint8 tensor). */
+size_t ftl_state_bytes(const ftl_handle* h);
+int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes);
+
+/* State introspection for parity tests: byte offset / element count / dtype code of a named field
+ * ("rb_pos","rb_dbl","rb_int","env_int","env_dbl","traj","hist","corr","snap_rects","snap_win").
+ * dtype: 0 i32, 1 f32, 2 f64.  per_env = elements per env (fields are [n_envs][per_env]). */
+int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype);
+
+/* reset() part 1 (ENV:461-492): hand over the scenario pool produced by reset-time generation. */
+int ftl_load_scenarios(ftl_handle* h, const ftl_scenarios* pool);
+
+/* reset() (ENV:494-543): place env e at scenario scen_idx[e] for every e with mask[e] != 0 (mask NULL = all),
+ * run the initial use_sensors (ENV:541) and write the first observation.  reward/done/status are zeroed. */
+int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const ftl_outputs* out, void* stream);
+
+/* step(action) (ENV:908-945) for all envs: action[n][2] = (speed px/frame, signed rotation deg/frame) as f64. */
+int ftl_step(ftl_handle* h, const double* action, const ftl_outputs* out, uint32_t flags, void* stream);
+
+const char* ftl_last_error(void);
+
+/* indices into the "env_int" state field */
+enum {
+    FTL_EI_SCEN = 0, FTL_EI_TARGET_ID, FTL_EI_LEADER_FINISHED, FTL_EI_DONE, FTL_EI_CRASH, FTL_EI_IN_BOX,
+    FTL_EI_ON_TRACE, FTL_EI_TOO_CLOSE, FTL_EI_STEP_COUNT, FTL_EI_FINISH_TIMER, FTL_EI_TRAJ_LEN,
+    FTL_EI_TRK_COUNTER, FTL_EI_CORR_LO, FTL_EI_CORR_HI, FTL_EI_SEED_END, FTL_EI_SNAP_COUNT,
+    FTL_EI_DYN_INDEX0, FTL_EI_DYN_INDEX1, FTL_EI_DYN_INDEX2, FTL_EI_DYN_INDEX3,
+    FTL_EI_ERROR, FTL_EI_EPISODES, FTL_EI_GREEN_COUNT, FTL_EI_SPARE, FTL_EI_COUNT
+};
+/* indices into the "env_dbl" state field; bear waypoints follow at FTL_ED_BEAR_POINTS + 2*b */
+enum { FTL_ED_ACC_PENALTY = 0, FTL_ED_OVERALL_REWARD, FTL_ED_SPARE0, FTL_ED_SPARE1, FTL_ED_BEAR_POINTS,
+       FTL_ED_COUNT = FTL_ED_BEAR_POINTS + 2 * FTL_MAX_BEARS };
+/* per robot: rb_dbl[5] and rb_int[8] */
+enum { FTL_RD_DIRECTION = 0, FTL_RD_SPEED, FTL_RD_ROT_SPEED, FTL_RD_DES_SPEED, FTL_RD_DES_ROT_SPEED, FTL_RD_COUNT };
+enum { FTL_RI_X = 0, FTL_RI_Y, FTL_RI_W, FTL_RI_H, FTL_RI_ROT_DIR, FTL_RI_DES_ROT_DIR, FTL_RI_SPARE0, FTL_RI_SPARE1, FTL_RI_COUNT };
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTL_H */

@@ -1,0 +1,398 @@
+#!/usr/bin/env python3
+"""Golden-vector generator -- runs ONLY in the build container (needs /root/reference).
+
+Executes the UNMODIFIED reference ``Game`` (``/root/reference/src/continuous_grid_arctic/
+follow_the_leader_continuous_env.py``) on top of the build-authored stand-ins for the two
+libraries the image lacks (``standins/pygame``, ``standins/gym``) and
+dumps, per episode, the post-``reset()`` scenario plus the per-step trace
+(action, obs, reward, done, info) as a small ``.npz`` under ``tests/golden/``.
+
+Determinism policy:
+  * ``pygame.time.get_ticks()`` seen by frame k (k = 1, 2, ... counted from ``reset()``) is k;
+  * actions enter the reference as Python floats (f64);
+  * ``seed(s)`` seeds ``random`` / ``np.random`` exactly as the reference does (``ENV:429-432``).
+
+Nothing here is imported by the product; the GPU box never runs this file.
+
+usage:  python tests/golden/gen/make_golden.py [--only NAME] [--pool P] [--jobs J]
+"""
+import argparse
+import io
+import json
+import math
+import os
+import sys
+import contextlib
+from collections import OrderedDict
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "standins"))
+sys.path.insert(0, "/root/reference/src")
+
+SENSORS_B = OrderedDict([
+    ("LeaderPositionsTracker_v2", {
+        "sensor_class": "LeaderPositionsTracker_v2", "eat_close_points": False,
+        "generate_corridor": True, "saving_period": 8,
+        "sensor_name": "LeaderPositionsTracker_v2", "start_corridor_behind_follower": True,
+        "corridor_length": 250, "corridor_width": 30}),
+    ("LeaderCorridor_lasers_all", {
+        "sensor_name": "LeaderCorridor_lasers_all", "sensor_class": "LeaderCorridor_Prev_lasers_v2",
+        "react_to_green_zone": True, "react_to_obstacles": True, "react_to_safe_corridor": True,
+        "lasers_count": 12, "laser_length": 100, "max_prev_obs": 5, "use_prev_obs": True,
+        "pad_sectors": False}),
+    ("LeaderCorridor_lasers_obstacles", {
+        "sensor_name": "LeaderCorridor_lasers_obstacles", "sensor_class": "LeaderCorridor_Prev_lasers_v2",
+        "react_to_green_zone": False, "react_to_obstacles": True, "react_to_safe_corridor": False,
+        "lasers_count": 24, "laser_length": 150, "max_prev_obs": 5, "use_prev_obs": True,
+        "pad_sectors": False}),
+])
+
+SENSORS_D = OrderedDict([
+    ("LeaderPositionsTracker_v2", dict(SENSORS_B["LeaderPositionsTracker_v2"])),
+    ("LaserPrevSensor_180", {
+        "sensor_name": "LaserPrevSensor_180", "sensor_class": "LeaderCorridor_Prev_lasers_v2",
+        "react_to_green_zone": False, "react_to_obstacles": True, "react_to_safe_corridor": False,
+        "lasers_count": 36, "laser_length": 200, "max_prev_obs": 5, "use_prev_obs": True,
+        "pad_sectors": False, "first_laser_angle_offset": 0}),
+])
+
+# kwargs handed to the reference Game(**kwargs); "_post" = attribute patches applied to sensor
+# objects after each reset (config D: the reference rejects lasers_count=180 at construction,
+# SEN:761-762, so the documented interpretation sets it afterwards -- SURVEY.md 8(d)).
+CONFIGS = {
+    "A": dict(kwargs=dict(), post=None),
+    "B": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B), post=None),
+    "D": dict(kwargs=dict(bear_number=1, obstacle_number=100, follower_sensors=SENSORS_D),
+              post={"LaserPrevSensor_180": dict(lasers_count=180, laser_period=2.0)}),
+    # early-stopping variant of B (exercises ENV:1088-1107)
+    "B_es": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B,
+                             early_stopping={"max_distance_coef": 1.2, "low_reward": -100}), post=None),
+    # short horizon (exercises finished_by_time ENV:1129-1134 and the warm_start gate)
+    "B_short": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B, max_steps=450, warm_start=100), post=None),
+    # no dynamic obstacles (add_bear=False): long clean episodes -> "success" (ENV:1077-1087)
+    "B_nobear": dict(kwargs=dict(add_bear=False, follower_sensors=SENSORS_B), post=None),
+    # three bears (odd index -> _move_bear_v4), sensors of B
+    "B3": dict(kwargs=dict(bear_number=3, follower_sensors=SENSORS_B), post=None),
+}
+
+
+def import_reference():
+    import pygame  # stand-in
+    with contextlib.redirect_stdout(io.StringIO()):
+        import continuous_grid_arctic.follow_the_leader_continuous_env as ENV
+    return pygame, ENV
+
+
+class Runner:
+    """One reference Game with the deterministic tick installed."""
+
+    def __init__(self, config_name):
+        self.pygame, ENV = import_reference()
+        cfg = CONFIGS[config_name]
+        self.cfg = cfg
+        import copy
+        self.game = ENV.Game(**copy.deepcopy(cfg["kwargs"]))
+        self.frame = 0
+        orig = self.game.frame_step
+
+        def frame_step(action):
+            self.frame += 1
+            return orig(action)
+
+        self.game.frame_step = frame_step
+        self.pygame.time._ticks_fn = lambda: self.frame
+
+    def reset(self, seed):
+        g = self.game
+        g.seed(seed)
+        self.frame = 0
+        with contextlib.redirect_stdout(io.StringIO()):
+            # the reference's reset() runs use_sensors itself; for config D the sensor must be
+            # patched BEFORE that first scan, so intercept robot creation.
+            if self.cfg["post"]:
+                orig_create = g._create_robots
+                post = self.cfg["post"]
+
+                def create():
+                    orig_create()
+                    for sname, attrs in post.items():
+                        for k, v in attrs.items():
+                            setattr(g.follower.sensors[sname], k, v)
+                g._create_robots = create
+                try:
+                    obs = g.reset()
+                finally:
+                    g._create_robots = orig_create
+            else:
+                obs = g.reset()
+        return obs
+
+    def step(self, action):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return self.game.step((float(action[0]), float(action[1])))
+
+
+MISSION = {"in_progress": 0, "fail": 1, "success": 2, "finished_by_time": 3}
+AGENT = {"moving": 0, "crash": 1, "low_reward": 2, "too_far_from_leader": 3, "finished": 4}
+LEADER = {"moving": 0, "crash": 1, "finished": 2}
+
+
+def robot_record(r):
+    """[pos_x, pos_y (f32 values), direction, speed, rotation_speed] + rect + rotation_direction."""
+    rect = r.rectangle
+    return (np.array([r.position[0], r.position[1]], dtype=np.float32),
+            np.array([float(r.direction), float(r.speed), float(r.rotation_speed),
+                      float(r.desirable_speed), float(r.desirable_rotation_speed)], dtype=np.float64),
+            np.array([rect.x, rect.y, rect.w, rect.h, int(r.rotation_direction),
+                      int(r.desirable_rotation_direction)], dtype=np.int32))
+
+
+def scenario_of(g):
+    """Post-reset scenario = everything the step path needs that reset() produced
+    (ENV:434-543); unaffected by the use_sensors call at ENV:541."""
+    robots = [g.leader, g.follower] + list(g.game_dynamic_list)
+    pos, f64, i32 = zip(*[robot_record(r) for r in robots])
+    statics = [o for o in g.game_object_list if o is not g.leader and o is not g.follower]
+    srect = np.array([[o.rectangle.x, o.rectangle.y, o.rectangle.w, o.rectangle.h] for o in statics],
+                     dtype=np.int32).reshape(-1, 4)
+    traj = np.array([[float(p[0]), float(p[1])] for p in g.leader_factual_trajectory], dtype=np.float32).reshape(-1, 2)
+    # check that the f32 values survive the float() round trip exactly
+    for p, q in zip(g.leader_factual_trajectory, traj):
+        assert np.float32(p[0]) == q[0] and np.float32(p[1]) == q[1]
+    route = np.array(g.trajectory, dtype=np.float64).reshape(-1, 2)
+    return dict(robot_pos=np.stack(pos), robot_f64=np.stack(f64), robot_i32=np.stack(i32),
+                static_rects=srect, route=route, init_traj=traj,
+                found_target_point=np.array(bool(g.found_target_point)),
+                bear_points=np.array([[float(p[0]), float(p[1])] for p in getattr(g, "cur_points_for_bear", [])],
+                                     dtype=np.float64).reshape(-1, 2),
+                done_at_reset=np.array(bool(g.done)))
+
+
+def obs_record(g, obs, laser_names):
+    rec = {"num": np.asarray(obs["numerical_features"], dtype=np.float32),
+           "target": np.array([float(obs["leader_target_point"][0]), float(obs["leader_target_point"][1])])}
+    for n in laser_names:
+        a = np.asarray(obs[n])
+        rec["laser:" + n] = a.astype(np.float32) if a.dtype == np.float32 else a.astype(np.float64)
+    return rec
+
+
+def debug_record(g):
+    """Internal state used only to localise a parity failure (never an API contract)."""
+    robots = [g.leader, g.follower] + list(g.game_dynamic_list)
+    pos, f64, i32 = zip(*[robot_record(r) for r in robots])
+    d = dict(robot_pos=np.stack(pos), robot_f64=np.stack(f64), robot_i32=np.stack(i32),
+             counters=np.array([g.step_count, len(g.leader_factual_trajectory),
+                                len(g.green_zone_trajectory_points), g.cur_target_id,
+                                int(g.leader_finished), int(g.is_in_box), int(g.is_on_trace),
+                                int(g.follower_too_close), int(g.crash), int(g.done),
+                                -1 if g.finish_position_framestimer is None else g.finish_position_framestimer],
+                               dtype=np.int64),
+             acc=np.array([float(g.accumulated_penalty), float(g.overall_reward)]))
+    tr = g.follower.sensors.get("LeaderPositionsTracker_v2") if hasattr(g.follower, "sensors") else None
+    if tr is not None:
+        hist = np.array([[float(p[0]), float(p[1])] for p in tr.leader_positions_hist], dtype=np.float64).reshape(-1, 2)
+        corr = np.array([[float(c[0][0]), float(c[0][1]), float(c[1][0]), float(c[1][1])] for c in tr.corridor],
+                        dtype=np.float64).reshape(-1, 4)
+        isf64 = np.array([np.asarray(p).dtype == np.float64 for p in tr.leader_positions_hist], dtype=np.uint8)
+        d.update(trk=np.array([tr.saving_counter, len(hist), len(corr)], dtype=np.int64))
+        d["hist"] = hist
+        d["corr"] = corr
+        d["hist_isf64"] = isf64
+    if hasattr(g, "dynamics_index"):
+        d["dyn_index"] = np.array(g.dynamics_index, dtype=np.int64)
+    return d
+
+
+def chase_action(g, rng, noise):
+    """A simple pursuit policy (so that episodes are long and rewards non-trivial) + noise."""
+    f, l = g.follower, g.leader
+    # aim at a point max(min_distance*1.6, ..) behind the leader along the factual trajectory
+    tgt = g.leader_factual_trajectory[max(0, len(g.leader_factual_trajectory) - 70)]
+    dx, dy = float(tgt[0]) - float(f.position[0]), float(tgt[1]) - float(f.position[1])
+    want = math.degrees(math.atan2(dy, dx)) % 360.0
+    err = (want - float(f.direction) + 540.0) % 360.0 - 180.0
+    w = max(-f.max_rotation_speed, min(f.max_rotation_speed, err * 0.3))
+    dist = math.hypot(float(l.position[0]) - float(f.position[0]), float(l.position[1]) - float(f.position[1]))
+    v = f.max_speed if dist > g.min_distance * 2.4 else (0.0 if dist < g.min_distance * 1.5 else 0.9 * f.max_speed)
+    w += noise * rng.normal() * f.max_rotation_speed
+    v *= (1.0 - 0.3 * noise * rng.random())
+    w = max(-f.max_rotation_speed, min(f.max_rotation_speed, w))
+    return (float(v), float(w))
+
+
+def random_action(g, rng):
+    f = g.follower
+    v = rng.uniform(0.5, 1.0) * f.max_speed
+    w = float(np.clip(rng.normal(0.0, 0.2 * f.max_rotation_speed), -f.max_rotation_speed, f.max_rotation_speed))
+    return (float(v), w)
+
+
+def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_done=3):
+    r = Runner(config_name)
+    obs0 = r.reset(seed)
+    g = r.game
+    laser_names = [k for k, v in g.follower_sensors.items() if v.get("sensor_class", k) == "LeaderCorridor_Prev_lasers_v2"]
+    scen = scenario_of(g)
+    out = {"scen:" + k: v for k, v in scen.items()}
+    for k, v in obs_record(g, obs0, laser_names).items():
+        out["reset:" + k] = v
+    for k, v in debug_record(g).items():
+        out["reset_dbg:" + k] = v
+    rng = np.random.default_rng(1000 + seed)
+    acts, rews, dones, infos = [], [], [], []
+    obs_rows = {}
+    dbg_rows = {}
+    after_done = 0
+    for t in range(n_steps):
+        if policy == "chase":
+            a = chase_action(g, rng, 0.05)
+        elif policy == "chase_noisy":
+            a = chase_action(g, rng, 0.5)
+        elif policy == "random":
+            a = random_action(g, rng)
+        elif policy == "straight":
+            a = (0.225 * g.follower.max_speed / 0.25, 0.0)
+        else:
+            raise ValueError(policy)
+        obs, rew, done, info = r.step(a)
+        acts.append(a)
+        rews.append(float(rew))
+        dones.append(bool(done))
+        infos.append([MISSION[info["mission_status"]], AGENT[info["agent_status"]], LEADER[info["leader_status"]]])
+        for k, v in obs_record(g, obs, laser_names).items():
+            obs_rows.setdefault(k, []).append(v)
+        if t % debug_every == 0:
+            for k, v in debug_record(g).items():
+                dbg_rows.setdefault(k, []).append(v)
+        if done:
+            after_done += 1
+            if after_done >= stop_after_done:  # the reference keeps simulating after done (ENV:935-936)
+                break
+    out["actions"] = np.array(acts, dtype=np.float64)
+    out["reward"] = np.array(rews, dtype=np.float64)
+    out["done"] = np.array(dones, dtype=np.uint8)
+    out["info"] = np.array(infos, dtype=np.uint8)
+    for k, v in obs_rows.items():
+        out["obs:" + k] = np.stack(v)
+    for k, v in dbg_rows.items():
+        if k in ("hist", "corr", "hist_isf64"):
+            # ragged: pad to max length
+            m = max(len(x) for x in v)
+            w = v[0].shape[1:] if v[0].ndim > 1 else ()
+            arr = np.full((len(v), m) + tuple(w), np.nan if k != "hist_isf64" else 255,
+                          dtype=np.float64 if k != "hist_isf64" else np.uint8)
+            for i, x in enumerate(v):
+                arr[i, :len(x)] = x
+            out["dbg:" + k] = arr
+        else:
+            out["dbg:" + k] = np.stack(v)
+    meta = dict(config=config_name, seed=seed, policy=policy, n_steps=len(acts), debug_every=debug_every,
+                kwargs=json.loads(json.dumps(CONFIGS[config_name]["kwargs"], default=str)),
+                post=CONFIGS[config_name]["post"], laser_names=laser_names,
+                numpy=np.__version__, tick="frame k sees get_ticks()==k")
+    out["meta"] = np.array(json.dumps(meta))
+    return out
+
+
+# (name, config, seed, policy, steps)
+EPISODES = [
+    ("B_s12_straight", "B", 12, "straight", 300),
+    ("B_s1_chase", "B", 1, "chase", 520),
+    ("B_s3_chase_noisy", "B", 3, "chase_noisy", 300),
+    ("B_s5_random", "B", 5, "random", 200),
+    ("B_s7_random", "B", 7, "random", 200),
+    ("B_s21_chase", "B", 21, "chase", 300),
+    ("A_s0_chase", "A", 0, "chase", 200),
+    ("A_s4_random", "A", 4, "random", 150),
+    ("Bes_s2_random", "B_es", 2, "random", 200),
+    ("Bes_s6_chase", "B_es", 6, "chase_noisy", 200),
+    ("B3_s8_chase", "B3", 8, "chase", 250),
+    ("D_s2_chase", "D", 2, "chase", 60),
+    ("Bshort_s4_chase", "B_short", 4, "chase", 60),
+    ("Bshort_s9_random", "B_short", 9, "random", 60),
+    ("Bnobear_s1_chase", "B_nobear", 1, "chase", 520),
+    ("Bnobear_s2_chase", "B_nobear", 2, "chase", 520),
+    ("Bnobear_s5_chase", "B_nobear", 5, "chase", 520),
+]
+
+
+def one_episode(args):
+    name, cfg, seed, policy, steps = args
+    out = run_episode(cfg, seed, policy, steps)
+    path = os.path.join(GOLDEN, "episode_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    return name, int(out["done"].sum()), len(out["reward"]), float(out["reward"].sum())
+
+
+def pool_worker(args):
+    config_name, seeds = args
+    r = Runner(config_name)
+    recs = []
+    for s in seeds:
+        r.reset(s)
+        sc = scenario_of(r.game)
+        if not bool(sc["found_target_point"]) or bool(sc["done_at_reset"]):
+            continue
+        sc["seed"] = np.array(s)
+        recs.append(sc)
+    return recs
+
+
+def make_pool(config_name, n_seeds, jobs, seed0=0):
+    """Scenario pool for bench.py / full-size property tests: post-reset scenarios of the reference
+    for python seeds seed0..seed0+n_seeds-1 (D*-failed scenarios dropped)."""
+    import multiprocessing as mp
+    chunks = [list(range(seed0 + i, seed0 + n_seeds, jobs)) for i in range(jobs)]
+    with mp.Pool(jobs) as p:
+        parts = p.map(pool_worker, [(config_name, c) for c in chunks])
+    recs = sorted([r for part in parts for r in part], key=lambda r: int(r["seed"]))
+    P = len(recs)
+    S = recs[0]["static_rects"].shape[0]
+    R = recs[0]["robot_pos"].shape[0]
+    wmax = max(r["route"].shape[0] for r in recs)
+    tmax = max(r["init_traj"].shape[0] for r in recs)
+    out = dict(seed=np.array([int(r["seed"]) for r in recs], dtype=np.int32),
+               static_rects=np.stack([r["static_rects"] for r in recs]).astype(np.int16 if True else np.int32),
+               robot_pos=np.stack([r["robot_pos"] for r in recs]),
+               robot_dir=np.stack([r["robot_f64"][:, 0] for r in recs]),
+               robot_rect=np.stack([r["robot_i32"][:, :4] for r in recs]).astype(np.int16),
+               route=np.zeros((P, wmax, 2), dtype=np.int16), route_len=np.zeros(P, dtype=np.int32),
+               init_traj=np.zeros((P, tmax, 2), dtype=np.float32), init_traj_len=np.zeros(P, dtype=np.int32))
+    for i, r in enumerate(recs):
+        assert np.all(r["route"] == np.round(r["route"])) and np.abs(r["route"]).max() < 32000
+        out["route"][i, :len(r["route"])] = r["route"]
+        out["route_len"][i] = len(r["route"])
+        out["init_traj"][i, :len(r["init_traj"])] = r["init_traj"]
+        out["init_traj_len"][i] = len(r["init_traj"])
+    meta = dict(config=config_name, n_seeds=n_seeds, seed0=seed0, kept=P, S=S, R=R,
+                kwargs=json.loads(json.dumps(CONFIGS[config_name]["kwargs"], default=str)))
+    out["meta"] = np.array(json.dumps(meta))
+    path = os.path.join(GOLDEN, "pool_%s.npz" % config_name)
+    np.savez_compressed(path, **out)
+    print("pool", config_name, "kept", P, "of", n_seeds, "->", path, os.path.getsize(path), "bytes")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--pool", type=int, default=0, help="also (re)generate scenario pools with this many seeds")
+    ap.add_argument("--pool-config", default="B")
+    ap.add_argument("--jobs", type=int, default=8)
+    ap.add_argument("--no-episodes", action="store_true")
+    a = ap.parse_args()
+    if not a.no_episodes:
+        todo = [e for e in EPISODES if a.only is None or a.only in e[0]]
+        import multiprocessing as mp
+        with mp.Pool(min(a.jobs, len(todo))) as p:
+            for name, ndone, n, ret in p.imap_unordered(one_episode, todo):
+                print("episode %-20s steps=%4d done_steps=%d return=%.2f" % (name, n, ndone, ret), flush=True)
+    if a.pool:
+        make_pool(a.pool_config, a.pool, a.jobs)
+
+
+if __name__ == "__main__":
+    main()
