@@ -1,0 +1,216 @@
+// ftl_abi.hip -- host side of the C-ABI declared in include/ftl.h: config validation, state layout, kernel launch.
+// There is no CPU fallback anywhere in this file: every entry point that computes launches the HIP kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "ftl_device.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+struct Field { const char* name; size_t offset, per_env; int dtype; };
+
+}  // namespace
+
+struct ftl_handle {
+    FtlDevParams P;          // host copy of the frozen parameters
+    FtlDevParams* dP;        // device copy read by the kernel (library-owned, ~1 KB)
+    bool dirty;
+    int device;
+    size_t state_bytes;
+    Field fields[10];
+    bool bound, have_scen;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int validate(const ftl_config& c, std::string& why) {
+    char buf[256];
+#define REQ(cond, ...) do { if (!(cond)) { snprintf(buf, sizeof buf, __VA_ARGS__); why = buf; return FTL_E_INVALID; } } while (0)
+    REQ(c.abi_version == FTL_ABI_VERSION, "abi_version %d != %d", c.abi_version, FTL_ABI_VERSION);
+    REQ(c.width > 0 && c.height > 0, "bad field size");
+    REQ(c.frames_per_step > 0, "frames_per_step must be positive");
+    REQ(c.trajectory_saving_period > 0, "trajectory_saving_period must be positive");
+    REQ(c.n_static >= 0 && c.n_static <= 4096, "n_static out of range");
+    REQ(c.n_bears >= 0 && c.n_bears <= FTL_MAX_BEARS, "n_bears out of range (0..%d)", FTL_MAX_BEARS);
+    REQ(c.n_lasers >= 0 && c.n_lasers <= FTL_MAX_LASERS, "n_lasers out of range");
+    REQ(c.n_lasers == 0 || c.has_tracker, "ray sensors need the tracker (classes.py:280 would raise NameError)");
+    REQ(c.traj_cap >= 8 && c.corr_cap >= 8 && c.corr_cap <= 512 && c.route_cap >= 2 && c.init_traj_cap >= 1, "bad capacities");
+    REQ(c.init_traj_cap <= c.traj_cap, "init_traj_cap > traj_cap");
+    if (c.has_tracker) {
+        REQ(c.tracker_saving_period > 0, "tracker saving_period must be positive");
+        REQ(c.corridor_length > 0 && c.corridor_width > 0, "corridor_length / corridor_width must be positive");
+    }
+    for (int k = 0; k < c.n_lasers; k++) {
+        const ftl_laser_cfg& l = c.lasers[k];
+        REQ(l.count > 0 && l.count <= 1024, "laser %d: bad lasers_count", k);
+        REQ(l.history > 0 && l.history <= FTL_HMAX, "laser %d: max_prev_obs must be in 1..%d", k, FTL_HMAX);
+        REQ(l.react_obstacles >= 0 && l.react_obstacles <= 3, "laser %d: bad react_to_obstacles", k);
+        REQ(l.length > 0, "laser %d: bad laser_length", k);
+    }
+#undef REQ
+    return FTL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ftl_last_error(void) { return g_err.c_str(); }
+
+size_t ftl_sizeof_config(void) { return sizeof(ftl_config); }
+size_t ftl_sizeof_scenarios(void) { return sizeof(ftl_scenarios); }
+size_t ftl_sizeof_outputs(void) { return sizeof(ftl_outputs); }
+
+int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle** out) {
+    if (!cfg || !out) return fail(FTL_E_INVALID, "null argument");
+    if (n_envs <= 0) return fail(FTL_E_INVALID, "n_envs must be positive");
+    if (device < 0) return fail(FTL_E_INVALID, "device < 0: this library has no CPU path");
+    std::string why;
+    int rc = validate(*cfg, why);
+    if (rc) return fail(rc, why);
+    ftl_handle* h = new (std::nothrow) ftl_handle();
+    if (!h) return fail(FTL_E_DEVICE, "out of host memory");
+    memset(&h->P, 0, sizeof h->P);
+    h->P.cfg = *cfg;
+    h->device = device;
+    h->bound = false; h->have_scen = false; h->dP = nullptr; h->dirty = true;
+    FtlDevParams& P = h->P;
+    P.n_envs = n_envs;
+    P.R = 2 + cfg->n_bears;
+    int off = 0, hmax = 1, rays = 0;
+    for (int k = 0; k < cfg->n_lasers; k++) {
+        P.cfg.lasers[k].out_offset = off;
+        off += cfg->lasers[k].history * cfg->lasers[k].count;
+        hmax = cfg->lasers[k].history > hmax ? cfg->lasers[k].history : hmax;
+        P.rays_k[k] = rays; rays += cfg->lasers[k].count;
+    }
+    P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
+    // state layout: one region per field, [n_envs][per_env], 256-byte aligned
+    const size_t n = (size_t)n_envs;
+    struct { const char* name; size_t per_env; int dtype; size_t esz; } spec[10] = {
+        {"rb_pos", (size_t)P.R * 2, 1, 4}, {"rb_dbl", (size_t)P.R * FTL_RD_COUNT, 2, 8}, {"rb_int", (size_t)P.R * FTL_RI_COUNT, 0, 4},
+        {"env_int", FTL_EI_COUNT, 0, 4}, {"env_dbl", FTL_ED_COUNT, 2, 8}, {"traj", (size_t)cfg->traj_cap * 2, 1, 4},
+        {"hist", (size_t)cfg->corr_cap * 2, 2, 8}, {"corr", (size_t)cfg->corr_cap * 4, 2, 8},
+        {"snap_rects", (size_t)hmax * (P.R - 1) * 4, 0, 4}, {"snap_win", (size_t)hmax * 4, 0, 4}};
+    size_t cur = 0;
+    for (int i = 0; i < 10; i++) {
+        cur = align_up(cur, 256);
+        h->fields[i] = Field{spec[i].name, cur, spec[i].per_env, spec[i].dtype};
+        cur += spec[i].per_env * spec[i].esz * n;
+    }
+    h->state_bytes = align_up(cur, 256);
+    P.lds_bytes = (int)(((size_t)((cfg->n_static + 3) & ~3) * 16 + 16) + FTL_DCHUNK * 16 + (size_t)hmax * (P.R - 1) * 16 + (size_t)cfg->corr_cap * 16);
+    if (P.lds_bytes > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
+    *out = h;
+    return FTL_OK;
+}
+
+void ftl_destroy(ftl_handle* h) {
+    if (!h) return;
+    if (h->dP) { (void)hipSetDevice(h->device); (void)hipFree(h->dP); }
+    delete h;
+}
+
+int32_t ftl_lasers_len(const ftl_handle* h) { return h ? h->P.lasers_len : 0; }
+
+int ftl_get_config(const ftl_handle* h, ftl_config* out) {
+    if (!h || !out) return fail(FTL_E_INVALID, "null argument");
+    *out = h->P.cfg;
+    return FTL_OK;
+}
+
+size_t ftl_state_bytes(const ftl_handle* h) { return h ? h->state_bytes : 0; }
+
+int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype) {
+    if (!h || !name) return fail(FTL_E_INVALID, "null argument");
+    for (int i = 0; i < 10; i++)
+        if (!strcmp(h->fields[i].name, name)) {
+            if (offset) *offset = h->fields[i].offset;
+            if (per_env) *per_env = h->fields[i].per_env;
+            if (dtype) *dtype = h->fields[i].dtype;
+            return FTL_OK;
+        }
+    return fail(FTL_E_INVALID, std::string("unknown state field ") + name);
+}
+
+int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes) {
+    if (!h || !dev_state) return fail(FTL_E_INVALID, "null argument");
+    if (bytes < h->state_bytes) return fail(FTL_E_INVALID, "state buffer too small");
+    if (((uintptr_t)dev_state) & 255) return fail(FTL_E_INVALID, "state buffer must be 256-byte aligned");
+    unsigned char* b = (unsigned char*)dev_state;
+    FtlDevParams& P = h->P;
+    P.rb_pos = (float*)(b + h->fields[0].offset); P.rb_dbl = (double*)(b + h->fields[1].offset); P.rb_int = (int32_t*)(b + h->fields[2].offset);
+    P.env_int = (int32_t*)(b + h->fields[3].offset); P.env_dbl = (double*)(b + h->fields[4].offset); P.traj = (float*)(b + h->fields[5].offset);
+    P.hist = (double*)(b + h->fields[6].offset); P.corr = (double*)(b + h->fields[7].offset);
+    P.snap_rects = (int32_t*)(b + h->fields[8].offset); P.snap_win = (int32_t*)(b + h->fields[9].offset);
+    h->bound = true; h->dirty = true;
+    return FTL_OK;
+}
+
+int ftl_load_scenarios(ftl_handle* h, const ftl_scenarios* pool) {
+    if (!h || !pool) return fail(FTL_E_INVALID, "null argument");
+    if (pool->n_scenarios <= 0) return fail(FTL_E_INVALID, "empty scenario pool");
+    if (!pool->robot_pos || !pool->robot_dir || !pool->robot_rect || !pool->route || !pool->route_len ||
+        !pool->init_traj || !pool->init_traj_len || (h->P.cfg.n_static > 0 && !pool->static_rects))
+        return fail(FTL_E_INVALID, "scenario pool has null arrays");
+    h->P.scen = *pool;
+    h->have_scen = true; h->dirty = true;
+    return FTL_OK;
+}
+
+static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    if (!h->dP) {
+        e = hipMalloc((void**)&h->dP, sizeof(FtlDevParams));
+        if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMalloc(params): ") + hipGetErrorString(e));
+        h->dirty = true;
+    }
+    if (h->dirty) {   // only after bind_state / load_scenarios, never on the steady-state step path
+        e = hipMemcpy(h->dP, &h->P, sizeof(FtlDevParams), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
+        h->dirty = false;
+    }
+    hipLaunchKernelGGL(ftl_env_kernel, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_bytes, (hipStream_t)stream, h->dP, call);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+    return FTL_OK;
+}
+
+static int check_out(const ftl_handle* h, const ftl_outputs* out) {
+    if (!out || !out->obs_num || !out->target || !out->reward || !out->done || !out->status || (h->P.lasers_len > 0 && !out->lasers))
+        return fail(FTL_E_INVALID, "output arrays missing");
+    return FTL_OK;
+}
+
+int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const ftl_outputs* out, void* stream) {
+    if (!h || !scen_idx) return fail(FTL_E_INVALID, "null argument");
+    if (!h->bound) return fail(FTL_E_STATE, "ftl_bind_state has not been called");
+    if (!h->have_scen) return fail(FTL_E_STATE, "ftl_load_scenarios has not been called");
+    int rc = check_out(h, out);
+    if (rc) return rc;
+    FtlCall call; call.mode = 1; call.scen_idx = scen_idx; call.mask = mask; call.out = *out; call.action = nullptr; call.flags = 0;
+    return launch(h, call, stream);
+}
+
+int ftl_step(ftl_handle* h, const double* action, const ftl_outputs* out, uint32_t flags, void* stream) {
+    if (!h || !action) return fail(FTL_E_INVALID, "null argument");
+    if (!h->bound) return fail(FTL_E_STATE, "ftl_bind_state has not been called");
+    if (!h->have_scen) return fail(FTL_E_STATE, "ftl_load_scenarios has not been called");
+    int rc = check_out(h, out);
+    if (rc) return rc;
+    FtlCall call; call.mode = 0; call.action = action; call.out = *out; call.flags = flags; call.scen_idx = nullptr; call.mask = nullptr;
+    return launch(h, call, stream);
+}
+
+}  // extern "C"

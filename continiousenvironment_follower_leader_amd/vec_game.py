@@ -1,0 +1,184 @@
+"""``VecGame`` -- N independent follow-the-leader environments advanced by one HIP kernel launch per
+``step()`` (the batched counterpart of the reference's ``Game.reset/step``,
+follow_the_leader_continuous_env.py:434-543, 908-945).
+
+PyTorch is used for plumbing only: it owns the device buffers (state blob, scenario pool, outputs) and the
+stream; all arithmetic happens in ``libftl_hip.so`` behind the C-ABI of ``include/ftl.h``."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, abi
+from .config import GameConfig, make_config
+
+_DT = {0: torch.int32, 1: torch.float32, 2: torch.float64}
+
+
+class ScenarioPool:
+    """Post-reset scenarios (the output of the reference's reset-time generation, ENV:434-539) as device arrays."""
+
+    def __init__(self, cfg: GameConfig, static_rects, robot_pos, robot_dir, robot_rect, routes, init_trajs, device):
+        c = cfg.c
+        P = len(robot_pos)
+        R = cfg.n_robots
+        sr = np.asarray(static_rects, np.int32).reshape(P, -1, 4)
+        if sr.shape[1] != c.n_static:
+            raise ValueError("scenario has %d static rects, config expects %d" % (sr.shape[1], c.n_static))
+        route = np.zeros((P, c.route_cap, 2), np.float64)
+        route_len = np.zeros(P, np.int32)
+        it = np.zeros((P, c.init_traj_cap, 2), np.float32)
+        it_len = np.zeros(P, np.int32)
+        for i in range(P):
+            r = np.asarray(routes[i], np.float64).reshape(-1, 2)
+            t = np.asarray(init_trajs[i], np.float32).reshape(-1, 2)
+            if len(r) > c.route_cap:
+                raise ValueError("route of scenario %d has %d way-points > route_cap %d" % (i, len(r), c.route_cap))
+            if len(r) == 1:
+                raise ValueError("a one-point route makes the reference's reset raise IndexError (ENV:513)")
+            if len(t) > c.init_traj_cap:
+                raise ValueError("initial trajectory of scenario %d has %d points > init_traj_cap %d"
+                                 % (i, len(t), c.init_traj_cap))
+            route[i, :len(r)] = r
+            route_len[i] = len(r)
+            it[i, :len(t)] = t
+            it_len[i] = len(t)
+        dev = torch.device(device)
+        self.n = P
+        self.t = dict(
+            static_rects=torch.from_numpy(np.ascontiguousarray(sr)).to(dev),
+            robot_pos=torch.from_numpy(np.ascontiguousarray(np.asarray(robot_pos, np.float32).reshape(P, R, 2))).to(dev),
+            robot_dir=torch.from_numpy(np.ascontiguousarray(np.asarray(robot_dir, np.float64).reshape(P, R))).to(dev),
+            robot_rect=torch.from_numpy(np.ascontiguousarray(np.asarray(robot_rect, np.int32).reshape(P, R, 4))).to(dev),
+            route=torch.from_numpy(route).to(dev), route_len=torch.from_numpy(route_len).to(dev),
+            init_traj=torch.from_numpy(it).to(dev), init_traj_len=torch.from_numpy(it_len).to(dev))
+        s = abi.Scenarios()
+        s.n_scenarios = P
+        for k, v in self.t.items():
+            setattr(s, k, v.data_ptr())
+        self.c_struct = s
+
+    @classmethod
+    def from_npz(cls, cfg, path, device, limit=None):
+        z = np.load(path)
+        n = len(z["seed"]) if limit is None else min(limit, len(z["seed"]))
+        routes = [z["route"][i, :z["route_len"][i]].astype(np.float64) for i in range(n)]
+        trajs = [z["init_traj"][i, :z["init_traj_len"][i]] for i in range(n)]
+        return cls(cfg, z["static_rects"][:n].astype(np.int32), z["robot_pos"][:n], z["robot_dir"][:n],
+                   z["robot_rect"][:n].astype(np.int32), routes, trajs, device)
+
+
+class VecGame:
+    """N parallel envs on one GPU.
+
+    ``reset(scen_idx, mask)`` / ``step(action, auto_reset)`` return views of persistent device tensors:
+    ``obs_num`` f32[N,10] (numerical_features, ENV:1793-1802), ``lasers`` f32[N, sum_k H_k*N_k] (one
+    ``[H_k, N_k]`` block per ray sensor, ``laser_view(name)``), ``target`` f64[N,2], ``reward`` f64[N],
+    ``done`` u8[N], ``status`` u8[N,3] (mission/agent/leader codes of ``abi.MISSION/AGENT/LEADER``)."""
+
+    def __init__(self, n_envs, device="cuda:0", config: GameConfig = None, **game_kwargs):
+        self.cfg = config if config is not None else make_config(**game_kwargs)
+        self.n = int(n_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.FtlError("VecGame needs a ROCm device (got %s): there is no CPU path" % self.device)
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.lib.ftl_create(C.byref(self.cfg.c), self.n, dev_index, C.byref(h)), self.lib)
+        self.h = h
+        nbytes = self.lib.ftl_state_bytes(self.h)
+        with torch.cuda.device(self.device):
+            self.state = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = self.state.data_ptr()
+        self._state_off = (-base) % 256
+        _lib.check(self.lib.ftl_bind_state(self.h, base + self._state_off, nbytes), self.lib)
+        L = max(self.cfg.lasers_len, 1)
+        z = dict(device=self.device)
+        self.obs_num = torch.zeros(self.n, abi.FTL_OBS_NUM, dtype=torch.float32, **z)
+        self.lasers = torch.zeros(self.n, L, dtype=torch.float32, **z)
+        self.target = torch.zeros(self.n, 2, dtype=torch.float64, **z)
+        self.reward = torch.zeros(self.n, dtype=torch.float64, **z)
+        self.done = torch.zeros(self.n, dtype=torch.uint8, **z)
+        self.status = torch.zeros(self.n, 3, dtype=torch.uint8, **z)
+        o = abi.Outputs()
+        o.obs_num, o.lasers, o.target = self.obs_num.data_ptr(), self.lasers.data_ptr(), self.target.data_ptr()
+        o.reward, o.done, o.status = self.reward.data_ptr(), self.done.data_ptr(), self.status.data_ptr()
+        self._out = o
+        self.pool = None
+        self._fields = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ftl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ scenarios / reset / step
+    def load_scenarios(self, pool: ScenarioPool):
+        self.pool = pool
+        _lib.check(self.lib.ftl_load_scenarios(self.h, C.byref(pool.c_struct)), self.lib)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, scen_idx=None, mask=None):
+        if self.pool is None:
+            raise _lib.FtlError("load_scenarios() first")
+        if scen_idx is None:
+            scen_idx = torch.arange(self.n, dtype=torch.int32, device=self.device) % self.pool.n
+        scen_idx = torch.as_tensor(scen_idx, dtype=torch.int32, device=self.device).contiguous()
+        if scen_idx.numel() != self.n:
+            raise ValueError("scen_idx must have one entry per env")
+        if bool((scen_idx < 0).any()) or bool((scen_idx >= self.pool.n).any()):
+            raise ValueError("scen_idx out of range")
+        mptr = None
+        if mask is not None:
+            mask = torch.as_tensor(mask, dtype=torch.uint8, device=self.device).contiguous()
+            mptr = mask.data_ptr()
+        self._keep = (scen_idx, mask)
+        _lib.check(self.lib.ftl_reset(self.h, scen_idx.data_ptr(), mptr, C.byref(self._out), self._stream()), self.lib)
+        return self.obs_num, self.lasers
+
+    def step(self, action, auto_reset=False):
+        """action: f64[N,2] device tensor = (speed px/frame, signed rotation deg/frame) (ENV:927-933)."""
+        if action.dtype != torch.float64 or not action.is_contiguous() or action.device != self.device \
+                or tuple(action.shape) != (self.n, 2):
+            raise ValueError("action must be a contiguous float64 [n_envs, 2] tensor on %s" % self.device)
+        flags = abi.FTL_STEP_AUTO_RESET if auto_reset else 0
+        _lib.check(self.lib.ftl_step(self.h, action.data_ptr(), C.byref(self._out), flags, self._stream()), self.lib)
+        return self.obs_num, self.lasers, self.reward, self.done, self.status
+
+    # ------------------------------------------------------------------ views
+    def laser_view(self, name):
+        for l in self.cfg.lasers:
+            if l.name == name:
+                return self.lasers[:, l.out_offset:l.out_offset + l.history * l.count].view(self.n, l.history, l.count)
+        raise KeyError(name)
+
+    def state_field(self, name):
+        """Typed [n_envs, per_env] view of a named field of the state blob (parity tests / tracker obs)."""
+        if name not in self._fields:
+            off, per, dt = C.c_size_t(), C.c_size_t(), C.c_int32()
+            _lib.check(self.lib.ftl_state_field(self.h, name.encode(), C.byref(off), C.byref(per), C.byref(dt)), self.lib)
+            tdt = _DT[dt.value]
+            esz = torch.empty((), dtype=tdt).element_size()
+            a = self._state_off + off.value
+            self._fields[name] = self.state[a:a + per.value * esz * self.n].view(tdt).view(self.n, per.value)
+        return self._fields[name]
+
+    def tracker_obs(self, env):
+        """(leader_positions_hist, corridor) of one env, as the reference returns them under the tracker key
+        (sensors.py:324-325): hist f64[C,2]; corridor f64[C,2(right/left),2]."""
+        ei = self.state_field("env_int")[env].cpu().numpy()
+        lo, hi = int(ei[abi.EI_CORR_LO]), int(ei[abi.EI_CORR_HI])
+        cap = self.cfg.c.corr_cap
+        idx = torch.arange(lo, hi, device=self.device) % cap
+        hist = self.state_field("hist")[env].view(cap, 2)[idx].cpu().numpy()
+        corr = self.state_field("corr")[env].view(cap, 2, 2)[idx].cpu().numpy()
+        return hist, corr

@@ -1,0 +1,148 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path behind the C-ABI against
+(1) the golden episodes recorded from the UNMODIFIED reference and (2) the CPU oracle on seeded batches.
+
+Bar (BASELINE.json north_star): collision / done flags, info codes, integer hitboxes and counters bit-exact;
+float positions, sensor readings and reward within 1e-5 (observations are float32, so "1e-5 or one f32 ulp")."""
+import numpy as np
+import pytest
+import torch
+
+from continiousenvironment_follower_leader_amd import abi
+from golden_util import GOLDEN, close, config_for, episode_names, load_episode, scenario_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(cfg, n, scen_list):
+    from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
+    env = VecGame(n, device="cuda:0", config=cfg)
+    pool = ScenarioPool(cfg, np.stack([s["static_rects"] for s in scen_list]), np.stack([s["robot_pos"] for s in scen_list]),
+                        np.stack([s["robot_dir"] for s in scen_list]), np.stack([s["robot_rect"] for s in scen_list]),
+                        [s["route"] for s in scen_list], [s["init_traj"] for s in scen_list], "cuda:0")
+    env.load_scenarios(pool)
+    return env
+
+
+def _robots(env, e=0):
+    R = env.cfg.n_robots
+    pos = env.state_field("rb_pos")[e].view(R, 2).cpu().numpy()
+    dbl = env.state_field("rb_dbl")[e].view(R, abi.RD_COUNT).cpu().numpy()
+    ints = env.state_field("rb_int")[e].view(R, abi.RI_COUNT).cpu().numpy()
+    return pos, dbl, ints
+
+
+@pytest.mark.parametrize("name", episode_names())
+def test_hip_matches_reference_episode(name):
+    z, meta = load_episode(name)
+    cfg = config_for(meta, scen_route_len=len(z["scen:route"]))
+    scen = scenario_arrays(z)
+    n = 3   # the same episode in three envs: exercises multi-workgroup launches and env indexing
+    env = _vec(cfg, n, [scen])
+    env.reset(torch.zeros(n, dtype=torch.int32))
+    torch.cuda.synchronize()
+    lnames = meta["laser_names"]
+
+    def check(tag, t):
+        num = env.obs_num.cpu().numpy()
+        ref = z[tag + ":num"] if t is None else z[tag + ":num"][t]
+        for e in range(n):
+            assert close(num[e], ref).all(), (name, t, e, "num", num[e] - ref)
+        for ln in lnames:
+            got = env.laser_view(ln).cpu().numpy()
+            ref = z[tag + ":laser:" + ln] if t is None else z[tag + ":laser:" + ln][t]
+            assert got.shape[1:] == ref.shape
+            for e in range(n):
+                assert close(got[e], ref).all(), (name, t, e, ln, np.abs(got[e] - ref).max())
+        reft = z[tag + ":target"] if t is None else z[tag + ":target"][t]
+        assert np.array_equal(env.target.cpu().numpy()[0], reft), (name, t, "target")
+
+    check("reset", None)
+    acts = z["actions"]
+    for t in range(len(acts)):
+        a = torch.tensor(np.tile(acts[t], (n, 1)), dtype=torch.float64, device="cuda:0")
+        env.step(a)
+        check("obs", t)
+        rew = env.reward.cpu().numpy(); done = env.done.cpu().numpy(); st = env.status.cpu().numpy()
+        for e in range(n):
+            assert abs(rew[e] - z["reward"][t]) <= 1e-5, (name, t, rew[e], z["reward"][t])
+            assert bool(done[e]) == bool(z["done"][t]), (name, t, "done")
+            assert tuple(st[e]) == tuple(z["info"][t]), (name, t, st[e], z["info"][t])
+        # internal state against the reference's own objects
+        pos, dbl, ints = _robots(env, n - 1)
+        assert np.array_equal(ints[:, :6], z["dbg:robot_i32"][t]), (name, t, "hitboxes / rotation dirs", ints[:, :6], z["dbg:robot_i32"][t])
+        assert close(pos, z["dbg:robot_pos"][t]).all(), (name, t, "positions")
+        assert np.allclose(dbl, z["dbg:robot_f64"][t], rtol=0, atol=1e-9), (name, t, "controller state")
+        ei = env.state_field("env_int")[n - 1].cpu().numpy()
+        cnt = z["dbg:counters"][t]
+        got = [ei[abi.EI_STEP_COUNT], ei[abi.EI_TRAJ_LEN], ei[abi.EI_GREEN_COUNT], ei[abi.EI_TARGET_ID], ei[abi.EI_LEADER_FINISHED],
+               ei[abi.EI_IN_BOX], ei[abi.EI_ON_TRACE], ei[abi.EI_TOO_CLOSE], ei[abi.EI_CRASH], ei[abi.EI_DONE], ei[abi.EI_FINISH_TIMER]]
+        assert list(cnt) == [int(v) for v in got], (name, t, "counters", cnt, got)
+        assert ei[abi.EI_ERROR] == 0
+        if "dbg:trk" in z:
+            tr = z["dbg:trk"][t]
+            assert int(tr[0]) == ei[abi.EI_TRK_COUNTER] and int(tr[1]) == ei[abi.EI_CORR_HI] - ei[abi.EI_CORR_LO], (name, t, tr, ei)
+            hist, corr = env.tracker_obs(n - 1)
+            assert np.allclose(hist, z["dbg:hist"][t][:int(tr[1])], rtol=0, atol=1e-9), (name, t, "tracker history")
+            assert np.allclose(corr.reshape(-1, 4), z["dbg:corr"][t][:int(tr[2])], rtol=0, atol=1e-9), (name, t, "corridor")
+        if "dbg:dyn_index" in z:
+            nb = z["dbg:dyn_index"].shape[1]
+            assert np.array_equal(ei[abi.EI_DYN_INDEX0:abi.EI_DYN_INDEX0 + nb], z["dbg:dyn_index"][t])
+    env.close()
+
+
+def _pool_scenarios(limit):
+    z = np.load(GOLDEN + "/pool_B.npz")
+    out = []
+    for i in range(min(limit, len(z["seed"]))):
+        out.append(dict(static_rects=z["static_rects"][i].astype(np.int32), robot_pos=z["robot_pos"][i], robot_dir=z["robot_dir"][i],
+                        robot_rect=z["robot_rect"][i].astype(np.int32), route=z["route"][i, :z["route_len"][i]].astype(np.float64),
+                        init_traj=z["init_traj"][i, :z["init_traj_len"][i]]))
+    return out
+
+
+@pytest.mark.parametrize("n_envs,steps,policy", [(512, 60, "random"), (256, 120, "mixed")])
+def test_hip_matches_oracle_batch(n_envs, steps, policy):
+    """Seeded batch of config-B envs from the scenario pool: every output of every env and step against the oracle."""
+    import json
+    from oracle import OracleEnv
+    from golden_util import config_for
+    meta = json.loads(str(np.load(GOLDEN + "/pool_B.npz")["meta"]))
+    scen = _pool_scenarios(n_envs)
+    cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=max(len(s["route"]) for s in scen))
+    env = _vec(cfg, n_envs, scen)
+    idx = torch.arange(n_envs, dtype=torch.int32) % len(scen)
+    env.reset(idx)
+    oras = [OracleEnv(cfg) for _ in range(n_envs)]
+    lname = [l.name for l in cfg.lasers]
+    for e, o in enumerate(oras):
+        ob = o.reset(**scen[e % len(scen)])
+        assert close(env.obs_num[e].cpu().numpy(), ob["num"]).all()
+    rng = np.random.default_rng(7)
+    ms, mr = cfg.c.follower.max_speed, cfg.c.follower.max_rotation_speed
+    nmis = 0
+    for t in range(steps):
+        v = rng.uniform(0.5, 1.0, n_envs) * ms
+        w = np.clip(rng.normal(0, 0.2 * mr, n_envs), -mr, mr)
+        if policy == "mixed":
+            w[::3] = 0.0
+            v[1::4] = 0.0
+        a = np.stack([v, w], 1)
+        env.step(torch.tensor(a, dtype=torch.float64, device="cuda:0"))
+        num = env.obs_num.cpu().numpy(); las = env.lasers.cpu().numpy(); rew = env.reward.cpu().numpy()
+        done = env.done.cpu().numpy(); st = env.status.cpu().numpy(); tg = env.target.cpu().numpy()
+        ri = env.state_field("rb_int").cpu().numpy().reshape(n_envs, cfg.n_robots, abi.RI_COUNT)
+        for e, o in enumerate(oras):
+            ob, r, d, s = o.step(a[e])
+            assert bool(done[e]) == d and tuple(st[e]) == tuple(s), (t, e, "flags")
+            assert abs(rew[e] - r) <= 1e-5
+            assert close(num[e], ob["num"]).all(), (t, e, num[e] - ob["num"])
+            nmis += int((num[e] != ob["num"]).sum())
+            assert np.array_equal(tg[e], ob["target"])
+            for l in cfg.lasers:
+                got = las[e, l.out_offset:l.out_offset + l.history * l.count].reshape(l.history, l.count)
+                assert close(got, ob[l.name]).all(), (t, e, l.name, np.abs(got - ob[l.name]).max())
+            dbg = o.debug()
+            assert np.array_equal(ri[e][:, :6], dbg["robot_i32"]), (t, e, "hitboxes")
+    # float32 observations are expected to be bit-identical except for rare last-ulp trig differences
+    assert nmis <= 4, nmis
+    env.close()
