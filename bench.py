@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched Game.step() hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch: ONE launch of the HIP kernel advancing every env of this
+rank by one Game.step() (frames_per_step frames + one sensor scan), with auto-reset of finished episodes from the
+scenario pool inside the same launch.  Workload (BASELINE.json): config B -- 35 static + 2 walls + 1 dynamic
+obstacle, LeaderPositionsTracker_v2 + LeaderCorridor_Prev_lasers_v2 x2 (12 rays all edges, 24 rays obstacles,
+5-deep history), 65,536 parallel envs per GPU.  Multi-GPU: independent env batches per rank (weak scaling), no
+data-path collective; one RCCL all_reduce of the 8-entry episode-metrics vector after the timed region.
+
+Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+                bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_ENV_STEP = 4096        # algorithmic HBM bytes per env-step, config B
+
+
+def make_actions(cfg, n, n_sets, seed, device):
+    """Synthetic policy output, resident in HBM before the timed region: v ~ U[0.5,1]*max_speed,
+    w ~ N(0, 0.2*max_rot) clipped to the action box, float64 as the reference's Python floats."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    ms, mr = cfg.c.follower.max_speed, cfg.c.follower.max_rotation_speed
+    v = (0.5 + 0.5 * torch.rand(n_sets, n, generator=g, dtype=torch.float64)) * ms
+    w = torch.clamp(torch.randn(n_sets, n, generator=g, dtype=torch.float64) * (0.2 * mr), -mr, mr)
+    return torch.stack([v, w], dim=-1).contiguous().to(device)
+
+
+def cpu_baseline(cfg, pool_path, n_envs, steps, seed):
+    """The CPU oracle (oracle/ftl_oracle.c, a port of the reference's algorithm; the reference itself is Python
+    and cannot travel to the GPU box) timed on this host's cores with OpenMP over envs -- a REPORTED baseline on a
+    bounded sample of the same workload, not the thing measured above."""
+    import ctypes as C
+    from oracle import OracleEnv, load_oracle
+    z = np.load(pool_path)
+    P = len(z["seed"])
+    # the one-GPU box grants a 16-core share even though more cores are visible: never oversubscribe it
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("FTL_CPU_THREADS", "16")))
+    lib = load_oracle()
+    envs = []
+    for e in range(n_envs):
+        i = e % P
+        o = OracleEnv(cfg)
+        o.reset(static_rects=z["static_rects"][i].astype(np.int32), robot_pos=z["robot_pos"][i], robot_dir=z["robot_dir"][i],
+                robot_rect=z["robot_rect"][i].astype(np.int32), route=z["route"][i, :z["route_len"][i]].astype(np.float64),
+                init_traj=z["init_traj"][i, :z["init_traj_len"][i]])
+        envs.append(o)
+    arr = (C.c_void_p * n_envs)(*[o.h for o in envs])
+    L = max(cfg.lasers_len, 1)
+    obs = np.zeros((n_envs, 10), np.float32); las = np.zeros((n_envs, L), np.float32); tg = np.zeros((n_envs, 2))
+    rew = np.zeros(n_envs); done = np.zeros(n_envs, np.uint8); st = np.zeros((n_envs, 3), np.uint8)
+    acts = make_actions(cfg, n_envs, steps, seed, "cpu").numpy()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    t0 = time.perf_counter()
+    for k in range(steps):
+        a = np.ascontiguousarray(acts[k])
+        lib.ftlo_step_batch(arr, n_envs, p(a), p(obs), p(las), p(tg), p(rew), p(done), p(st), cores)
+    dt = time.perf_counter() - t0
+    return dict(value=n_envs * steps / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample="%d config-B envs x %d steps of oracle/ftl_oracle.c (C restatement of the reference, OpenMP over envs, "
+                       "no auto-reset), %.1f s wall" % (n_envs, steps, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=4096)
+    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from golden_util import GOLDEN, config_for
+    from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
+    pool_path = os.path.join(GOLDEN, "pool_B.npz")
+    z = np.load(pool_path)
+    meta = json.loads(str(z["meta"]))
+    cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=int(z["route_len"].max()))
+    n = a.envs_per_gpu
+    env = VecGame(n, device=device, config=cfg)
+    pool = ScenarioPool.from_npz(cfg, pool_path, device)
+    env.load_scenarios(pool)
+    # env e of rank r starts from scenario (seed*1000003 + r*n + e) mod P; auto-reset walks on by n_envs
+    idx = (torch.arange(n, dtype=torch.int64) + a.seed * 1000003 + rank * n) % pool.n
+    env.reset(idx.to(torch.int32))
+    n_sets = 16
+    acts = make_actions(cfg, n, n_sets, a.seed * 7919 + rank, device)
+    torch.cuda.synchronize()
+
+    done_sum = torch.zeros((), dtype=torch.float64, device=device)
+    for k in range(a.warmup):
+        env.step(acts[k % n_sets], auto_reset=True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for k in range(a.steps):
+        env.step(acts[(a.warmup + k) % n_sets], auto_reset=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / a.steps          # HIP events on the launch stream: avg launch-to-launch duration
+
+    # episode metrics (the only collective of the path; off the timed region): [episodes, done_now, errors]
+    ei = env.state_field("env_int")
+    from continiousenvironment_follower_leader_amd import abi
+    metrics = torch.stack([ei[:, abi.EI_EPISODES].sum().double(), env.done.sum().double(),
+                           (ei[:, abi.EI_ERROR] != 0).sum().double(), env.reward.sum()])
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    total_envs = n * world
+    value = total_envs * a.steps / dt
+
+    if rank == 0:
+        launch_bytes = BYTES_PER_ENV_STEP * n
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "env-steps/sec at 65,536 parallel envs; 1/2/4/8 MI355X scaling",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config B: %d envs/GPU, 35 rocks + 2 walls + 1 dynamic obstacle, tracker_v2 + "
+                                   "LeaderCorridor_Prev_lasers_v2 x2 (12 rays all edges L=100, 24 rays obstacles L=150, H=5), "
+                                   "10 frames/step, auto-reset from a %d-scenario pool captured from the reference's reset()"
+                                   % (n, pool.n),
+                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "independent env shards x%d" % world,
+                       "episodes_finished": float(metrics[0].item()), "env_error_flags": float(metrics[2].item())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "ftl_env_kernel", "kernel_ms": kernel_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, pool_path, a.cpu_envs, a.cpu_steps, a.seed)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
