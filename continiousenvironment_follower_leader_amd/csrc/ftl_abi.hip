@@ -109,8 +109,10 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         cur += spec[i].per_env * spec[i].esz * n;
     }
     h->state_bytes = align_up(cur, 256);
-    P.lds_bytes = (int)(((size_t)((cfg->n_static + 3) & ~3) * 16 + 16) + FTL_DCHUNK * 16 + (size_t)hmax * (P.R - 1) * 16 + (size_t)cfg->corr_cap * 16);
-    if (P.lds_bytes > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
+    const size_t lds_static = (size_t)((cfg->n_static + 3) & ~3) * 16 + 16;
+    P.lds_frames = (int)(lds_static + FTL_DCHUNK * 16);
+    P.lds_rays = (int)(lds_static + (size_t)hmax * (P.R - 1) * 16 + (size_t)cfg->corr_cap * 16);
+    if (P.lds_frames > 64 * 1024 || P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
     *out = h;
     return FTL_OK;
 }
@@ -181,7 +183,9 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
         h->dirty = false;
     }
-    hipLaunchKernelGGL(ftl_env_kernel, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_bytes, (hipStream_t)stream, h->dP, call);
+    hipLaunchKernelGGL(ftl_frames_kernel, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_frames, (hipStream_t)stream, h->dP, call);
+    if (h->P.cfg.n_lasers > 0)
+        hipLaunchKernelGGL(ftl_rays_kernel, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
     return FTL_OK;

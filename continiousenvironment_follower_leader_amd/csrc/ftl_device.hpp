@@ -1,16 +1,21 @@
 // ftl_device.hpp -- CDNA4 (gfx950) device code of the batched Game.step().
 //
-// One 64-lane wavefront advances one environment (one 64-thread workgroup per env):
-//   * robots live on lanes 0..R-1 (0 leader, 1 follower, 2.. bears): the rate-limited controller, the f64
-//     sin/cos integrator and the integer-hitbox update of AbstractRobot.move() (reference utils/classes.py:134-182)
-//     run once per frame for ALL robots in lock-step, steering (classes.py:184-215) once for leader + bears;
-//   * integer-rect collision tests put one static obstacle on each lane and reduce with a ballot;
-//   * the green-zone window / closest-point searches of follow_the_leader_continuous_env.py:1828-1843,1906-1960
-//     stride the factual trajectory over the lanes and finish with a wave arg-min;
-//   * the LeaderCorridor_Prev_lasers_v2 ray casts (utils/sensors.py:883-962) put one RAY on each lane and walk the
-//     obstacle segments -- static rects, the H-deep history of dynamic rects and the corridor ring, all staged in
-//     LDS -- with wave-uniform control flow (uniform distance culling, LDS broadcast reads), keeping one nearest-hit
-//     accumulator per history snapshot in registers.
+// One 64-lane wavefront advances one environment (one 64-thread workgroup per env).  A step() is two launches on
+// the same stream, split where the live state is smallest:
+//
+//   ftl_frames_kernel  -- frames_per_step x Game.frame_step (follow_the_leader_continuous_env.py:947-1141), the two
+//       LeaderPositionsTracker_v2 scans of use_sensors (classes.py:263-267, 285-286; sensors.py:243-327), the history
+//       snapshot push of the ray sensors (sensors.py:896-897) and _get_obs (1789-1810):
+//       * robots live on lanes 0..R-1 (0 leader, 1 follower, 2.. bears): controller + f64 sin/cos integrator + integer
+//         hitbox update of AbstractRobot.move() (classes.py:134-182) run once per frame for ALL robots in lock-step,
+//         steering (classes.py:184-215) once for leader + bears;
+//       * integer-rect collision tests put one static obstacle on each lane and reduce with a ballot;
+//       * green-zone window / closest-point searches (1828-1843, 1906-1960) stride the factual trajectory over the
+//         lanes and finish with a wave arg-min.
+//   ftl_rays_kernel -- LeaderCorridor_Prev_lasers_v2.scan (sensors.py:883-962) for every ray sensor: one RAY per lane,
+//       obstacle segments (static rects, H-deep history of dynamic rects, f32 corridor ring) staged in LDS and walked
+//       with wave-uniform control flow (uniform distance culling, LDS broadcast reads); one nearest-hit accumulator
+//       per history snapshot in registers.
 // No MFMA: there is no dense contraction anywhere on this path.
 //
 // Numerics follow oracle/ftl_oracle.c operation by operation (same dtype flow, explicit fma only where numpy/BLAS
@@ -27,7 +32,7 @@
 
 struct FtlDevParams {
     ftl_config cfg;
-    int32_t n_envs, R, lasers_len, total_rays, hmax, lds_bytes;
+    int32_t n_envs, R, lasers_len, total_rays, hmax, lds_frames, lds_rays;
     int32_t rays_k[FTL_MAX_LASERS];   // first global ray id of sensor k
     // per-env state (views into the caller-owned state buffer), all [n_envs][...]
     float* rb_pos; double* rb_dbl; int32_t* rb_int; int32_t* env_int; double* env_dbl;
@@ -53,9 +58,44 @@ __device__ __forceinline__ double rl_d(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     return __hiloint2double(__builtin_amdgcn_readlane(hi, lane), __builtin_amdgcn_readlane(lo, lane));
 }
-__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------- scalar math shared by all phases
+// sin & cos of a float64 angle with |x| < ~1e5 rad (every angle on this path is below 15 rad): three-term Cody-Waite
+// reduction by pi/2 carrying the rounding tail, then the fdlibm minimax kernels on [-pi/4, pi/4] (< 1 ulp).  The
+// generic ocml sincos carries a Payne-Hanek path for huge arguments that costs registers and instructions here.
+__device__ __forceinline__ void sincos_bounded(double x, double& s, double& c) {
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00;
+    const double pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
+    double fn = rint(x * invpio2);
+    int n = (int)fn;
+    double t = x - fn * pio2_1;
+    double w = fn * pio2_2;
+    double r = t - w;
+    w = fn * pio2_2t - ((t - r) - w);
+    double y0 = r - w;
+    double y1 = (r - y0) - w;
+    // __kernel_sin(y0, y1, 1) / __kernel_cos(y0, y1)
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = y0 * y0;
+    double v = z * y0;
+    double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    double ww = z * z;
+    double rc = z * (C1 + z * (C2 + z * C3)) + (ww * ww) * (C4 + z * (C5 + z * C6));
+    double hz = 0.5 * z;
+    double wc = 1.0 - hz;
+    double kc = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+    int q = n & 3;
+    double sv = (q & 1) ? kc : ks;
+    double cv = (q & 1) ? ks : kc;
+    s = (q & 2) ? -sv : sv;
+    c = ((q + 1) & 2) ? -cv : cv;
+}
+
 // scipy distance.euclidean on two float32 points (snrm2: f32 differences, f64 accumulate, f32 result)
 __device__ __forceinline__ double euclid_f32(float ax, float ay, float bx, float by) {
     float dx = ax - bx, dy = ay - by;
@@ -89,7 +129,7 @@ __device__ __forceinline__ void rotate_size(int w, int h, double angle_deg, int&
         return;
     }
     double r = a * .01745329251994329, s, c;
-    sincos(r, &s, &c);
+    sincos_bounded(r, s, c);
     double cx = c * w, cy = c * h, sx = s * w, sy = s * h;
     double mx = fmax(fmax(fmax(fabs(cx + sy), fabs(cx - sy)), fabs(-cx + sy)), fabs(-cx - sy));
     double my = fmax(fmax(fmax(fabs(sx + cy), fabs(sx - cy)), fabs(-sx + cy)), fabs(-sx - cy));
@@ -98,7 +138,7 @@ __device__ __forceinline__ void rotate_size(int w, int h, double angle_deg, int&
 
 // numpy pairwise summation over all n elements (what np.sum does), operands read from LDS
 template <typename T>
-__device__ T pairwise_le128(const T* a, int n) {
+__device__ __forceinline__ T pairwise_le128(const T* a, int n) {
     if (n < 8) { T r = (T)0; for (int i = 0; i < n; i++) r += a[i]; return r; }
     T r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
     int i;
@@ -128,40 +168,49 @@ struct Robot {
     double direction, speed, rot_speed, des_speed, des_rot_speed;
     int rot_dir, des_rot_dir;
     int rx, ry, rw, rh;
-    // limits of this lane's robot kind
-    double min_speed, max_speed, max_rot, max_dv, max_drot;
-    int img_w, img_h;
+    // bears only: the way-point of the previous frame and the index into the way-point cycle (ENV:717-718)
+    double tgt_x, tgt_y;
+    int dyn_index;
 };
+struct Limits { double min_speed, max_speed, max_rot, max_dv, max_drot; int img_w, img_h; };
 
-__device__ __forceinline__ void command_turn(Robot& r, double des, int dir) {       // classes.py:109-117
-    r.des_rot_speed = (des <= r.max_rot) ? des : r.max_rot;
+__device__ __forceinline__ Limits lane_limits(const ftl_config& c, int lane) {
+    const ftl_robot_params& p = (lane == 0) ? c.leader : (lane == 1 ? c.follower : c.bear);
+    Limits L;
+    L.min_speed = p.min_speed; L.max_speed = p.max_speed; L.max_rot = p.max_rotation_speed;
+    L.max_dv = p.max_speed_change; L.max_drot = p.max_rotation_speed_change; L.img_w = p.img_w; L.img_h = p.img_h;
+    return L;
+}
+
+__device__ __forceinline__ void command_turn(Robot& r, const Limits& L, double des, int dir) {       // classes.py:109-117
+    r.des_rot_speed = (des <= L.max_rot) ? des : L.max_rot;
     r.des_rot_dir = dir;
 }
-__device__ __forceinline__ void command_forward(Robot& r, double s) {               // classes.py:119-127
-    if (s > r.max_speed) s = r.max_speed;
-    if (s < r.min_speed) s = r.min_speed;
+__device__ __forceinline__ void command_forward(Robot& r, const Limits& L, double s) {               // classes.py:119-127
+    if (s > L.max_speed) s = L.max_speed;
+    if (s < L.min_speed) s = L.min_speed;
     r.des_speed = s;
 }
 // classes.py:165-182 (controller 134-163 inlined); `active` lanes commit, the rest keep their state
-__device__ __forceinline__ void robot_move(Robot& r, bool active) {
+__device__ __forceinline__ void robot_move(Robot& r, const Limits& L, bool active) {
     // _turn_processing
     int rot_dir = r.rot_dir;
     if (rot_dir == 0) rot_dir = r.des_rot_dir;
     double change;
     if (rot_dir == r.des_rot_dir) {
         double needed = fabs(r.rot_speed - r.des_rot_speed);
-        change = (needed <= r.max_drot) ? needed : r.max_drot;
+        change = (needed <= L.max_drot) ? needed : L.max_drot;
         if (r.des_rot_speed < r.rot_speed) change = -1 * change;
     } else {
         double needed = fabs(r.des_rot_speed + r.rot_speed);
-        change = -((needed <= r.max_drot) ? needed : r.max_drot);
+        change = -((needed <= L.max_drot) ? needed : L.max_drot);
     }
     double nr = r.rot_speed + change;
     if (nr < 0) rot_dir = -1 * rot_dir;
     double rot_speed = fabs(nr);
     // _speed_processing
     double needed = fabs(r.speed - r.des_speed);
-    double dv = (r.max_dv <= needed) ? r.max_dv : needed;
+    double dv = (L.max_dv <= needed) ? L.max_dv : needed;
     if (r.speed > r.des_speed) dv = -1 * dv;
     double speed = r.speed + dv;
 
@@ -172,12 +221,12 @@ __device__ __forceinline__ void robot_move(Robot& r, bool active) {
         if (turning) {
             direction = angle_correction(direction + rot_dir * rot_speed);
             int nw, nh, cx = rx + (rw >> 1), cy = ry + (rh >> 1);
-            rotate_size(r.img_w, r.img_h, -direction, nw, nh);
+            rotate_size(L.img_w, L.img_h, -direction, nw, nh);
             rw = nw; rh = nh; rx = cx - (nw >> 1); ry = cy - (nh >> 1);
         }
     }
     double s, c;
-    sincos(direction * kDeg2Rad, &s, &c);
+    sincos_bounded(direction * kDeg2Rad, s, c);
     float mx = (float)(c * speed), my = (float)(s * speed);
     float px = r.px + mx, py = r.py + my;
     double dx = (double)px - (double)(rx + (rw >> 1));
@@ -188,8 +237,8 @@ __device__ __forceinline__ void robot_move(Robot& r, bool active) {
         r.px = px; r.py = py; r.rx = rx; r.ry = ry; r.rw = rw; r.rh = rh;
     }
 }
-// classes.py:184-215: steering toward (tx,ty); speed < 0 means "speed=None" (use the distance)
-__device__ __forceinline__ void steer_to_point(Robot& r, double tx, double ty, bool has_speed, double speed) {
+// classes.py:184-215: steering toward (tx,ty); has_speed false means "speed=None" (use the distance)
+__device__ __forceinline__ void steer_to_point(Robot& r, const Limits& L, double tx, double ty, bool has_speed, double speed) {
     double new_speed = has_speed ? speed : euclid_f64((double)r.px, (double)r.py, tx, ty);
     int desirable = (int)angle_to_point((double)r.px, (double)r.py, tx, ty);
     int cur = (int)r.direction;
@@ -201,8 +250,8 @@ __device__ __forceinline__ void steer_to_point(Robot& r, double tx, double ty, b
         if (cur - desirable > 180) { dir = 1; delta = (360 - cur) + desirable; }
         else { dir = -1; delta = cur - desirable; }
     }
-    command_turn(r, (double)delta, dir);
-    command_forward(r, new_speed);
+    command_turn(r, L, (double)delta, dir);
+    command_forward(r, L, new_speed);
 }
 
 __device__ __forceinline__ bool rects_collide(int ax, int ay, int aw, int ah, int bx, int by, int bw, int bh) {
@@ -221,7 +270,7 @@ __device__ __forceinline__ void wave_argmin(float& v, int& idx) {
     }
 }
 
-// ---------------------------------------------------------------- the environment held by one wave
+// ---------------------------------------------------------------- the environment held by one wave (frames kernel)
 struct EnvCtx {
     const FtlDevParams& P;
     const FtlCall& C;
@@ -229,18 +278,14 @@ struct EnvCtx {
     // LDS carve-up of this wave
     int4* s_static;      // [n_static]
     float* s_d;          // [FTL_DCHUNK] float / reused as double scratch of the tracker
-    int4* s_snaprect;    // [hmax][R-1]   leader + bears at each snapshot (ring order)
-    float4* s_corr;      // [corr_cap] f32-rounded (right.xy, left.xy) of the corridor ring
     // wave-uniform scalars
     int scen, cur_target_id, leader_finished, done, crash, is_in_box, is_on_trace, too_close;
     int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
-    int dyn_index[FTL_MAX_BEARS];
-    int error, episodes, green_count, green_len;
+    int error, episodes, green_count, green_len, scan_ok;
     double acc_penalty, overall_reward;
-    double bear_pt[FTL_MAX_BEARS][2];
     double cur_tx, cur_ty;
     int route_len;
-    Robot rb;            // this lane's robot (lanes >= R hold a benign dummy)
+    Robot rb;            // this lane's robot (lanes >= R hold a benign dummy that is never committed)
     __device__ EnvCtx(const FtlDevParams& p, const FtlCall& c) : P(p), C(c) {}
 };
 
@@ -249,36 +294,24 @@ __device__ __forceinline__ const double* route_ptr(const EnvCtx& E) {
 }
 __device__ __forceinline__ float* traj_ptr(const EnvCtx& E) { return E.P.traj + (size_t)E.env * E.P.cfg.traj_cap * 2; }
 
-__device__ __forceinline__ void set_robot_limits(EnvCtx& E) {
-    const ftl_config& c = E.P.cfg;
-    const ftl_robot_params& p = (E.lane == 0) ? c.leader : (E.lane == 1 ? c.follower : c.bear);
-    E.rb.min_speed = p.min_speed; E.rb.max_speed = p.max_speed; E.rb.max_rot = p.max_rotation_speed;
-    E.rb.max_dv = p.max_speed_change; E.rb.max_drot = p.max_rotation_speed_change;
-    E.rb.img_w = p.img_w; E.rb.img_h = p.img_h;
-}
-
-__device__ void stage_static(EnvCtx& E) {
-    const int4* src = reinterpret_cast<const int4*>(E.P.scen.static_rects) + (size_t)E.scen * E.P.cfg.n_static;
-    for (int s = E.lane; s < E.P.cfg.n_static; s += FTL_WAVE) E.s_static[s] = src[s];
-    E.route_len = E.P.scen.route_len[E.scen];
+__device__ __forceinline__ void stage_static(int4* s_static, const FtlDevParams& P, int scen, int lane) {
+    const int4* src = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)scen * P.cfg.n_static;
+    for (int s = lane; s < P.cfg.n_static; s += FTL_WAVE) s_static[s] = src[s];
 }
 
 // ---- load / store of the per-env state ------------------------------------------------------------------------
-__device__ void env_load(EnvCtx& E) {
+__device__ __forceinline__ void env_load(EnvCtx& E) {
     const FtlDevParams& P = E.P;
     const int* ei = P.env_int + (size_t)E.env * FTL_EI_COUNT;
+    const double* ed = P.env_dbl + (size_t)E.env * FTL_ED_COUNT;
     E.scen = ei[FTL_EI_SCEN]; E.cur_target_id = ei[FTL_EI_TARGET_ID]; E.leader_finished = ei[FTL_EI_LEADER_FINISHED];
     E.done = ei[FTL_EI_DONE]; E.crash = ei[FTL_EI_CRASH]; E.is_in_box = ei[FTL_EI_IN_BOX]; E.is_on_trace = ei[FTL_EI_ON_TRACE];
     E.too_close = ei[FTL_EI_TOO_CLOSE]; E.step_count = ei[FTL_EI_STEP_COUNT]; E.finish_timer = ei[FTL_EI_FINISH_TIMER];
     E.traj_len = ei[FTL_EI_TRAJ_LEN]; E.trk_counter = ei[FTL_EI_TRK_COUNTER]; E.corr_lo = ei[FTL_EI_CORR_LO];
     E.corr_hi = ei[FTL_EI_CORR_HI]; E.seed_end = ei[FTL_EI_SEED_END]; E.snap_count = ei[FTL_EI_SNAP_COUNT];
-#pragma unroll
-    for (int b = 0; b < FTL_MAX_BEARS; b++) E.dyn_index[b] = ei[FTL_EI_DYN_INDEX0 + b];
-    E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_SPARE];
-    const double* ed = P.env_dbl + (size_t)E.env * FTL_ED_COUNT;
+    E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
     E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
-#pragma unroll
-    for (int b = 0; b < FTL_MAX_BEARS; b++) { E.bear_pt[b][0] = ed[FTL_ED_BEAR_POINTS + 2 * b]; E.bear_pt[b][1] = ed[FTL_ED_BEAR_POINTS + 2 * b + 1]; }
+    E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1];
     int r = (E.lane < P.R) ? E.lane : 0;     // idle lanes mirror robot 0 (never committed)
     size_t ro = (size_t)E.env * P.R + r;
     E.rb.px = P.rb_pos[2 * ro]; E.rb.py = P.rb_pos[2 * ro + 1];
@@ -288,33 +321,27 @@ __device__ void env_load(EnvCtx& E) {
     const int* ri = P.rb_int + ro * FTL_RI_COUNT;
     E.rb.rx = ri[FTL_RI_X]; E.rb.ry = ri[FTL_RI_Y]; E.rb.rw = ri[FTL_RI_W]; E.rb.rh = ri[FTL_RI_H];
     E.rb.rot_dir = ri[FTL_RI_ROT_DIR]; E.rb.des_rot_dir = ri[FTL_RI_DES_ROT_DIR];
-    set_robot_limits(E);
-    stage_static(E);
-    const double* rt = route_ptr(E);
-    if (E.route_len == 0) { E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1]; }
-    else {
-        int id = E.cur_target_id < E.route_len ? E.cur_target_id : E.route_len - 1;   // cur_target_point freezes at the last waypoint
-        E.cur_tx = rt[2 * id]; E.cur_ty = rt[2 * id + 1];
-    }
+    int b = (E.lane >= 2 && E.lane < P.R) ? E.lane - 2 : 0;
+    E.rb.tgt_x = ed[FTL_ED_BEAR_POINTS + 2 * b]; E.rb.tgt_y = ed[FTL_ED_BEAR_POINTS + 2 * b + 1];
+    E.rb.dyn_index = ei[FTL_EI_DYN_INDEX0 + b];
+    stage_static(E.s_static, P, E.scen, E.lane);
+    E.route_len = P.scen.route_len[E.scen];
 }
 
-__device__ void env_store(EnvCtx& E) {
+__device__ __forceinline__ void env_store(EnvCtx& E) {
     const FtlDevParams& P = E.P;
+    int* ei = P.env_int + (size_t)E.env * FTL_EI_COUNT;
+    double* ed = P.env_dbl + (size_t)E.env * FTL_ED_COUNT;
     if (E.lane == 0) {
-        int* ei = P.env_int + (size_t)E.env * FTL_EI_COUNT;
         ei[FTL_EI_SCEN] = E.scen; ei[FTL_EI_TARGET_ID] = E.cur_target_id; ei[FTL_EI_LEADER_FINISHED] = E.leader_finished;
         ei[FTL_EI_DONE] = E.done; ei[FTL_EI_CRASH] = E.crash; ei[FTL_EI_IN_BOX] = E.is_in_box; ei[FTL_EI_ON_TRACE] = E.is_on_trace;
         ei[FTL_EI_TOO_CLOSE] = E.too_close; ei[FTL_EI_STEP_COUNT] = E.step_count; ei[FTL_EI_FINISH_TIMER] = E.finish_timer;
         ei[FTL_EI_TRAJ_LEN] = E.traj_len; ei[FTL_EI_TRK_COUNTER] = E.trk_counter; ei[FTL_EI_CORR_LO] = E.corr_lo;
         ei[FTL_EI_CORR_HI] = E.corr_hi; ei[FTL_EI_SEED_END] = E.seed_end; ei[FTL_EI_SNAP_COUNT] = E.snap_count;
-#pragma unroll
-        for (int b = 0; b < FTL_MAX_BEARS; b++) ei[FTL_EI_DYN_INDEX0 + b] = E.dyn_index[b];
-        ei[FTL_EI_ERROR] = E.error; ei[FTL_EI_EPISODES] = E.episodes; ei[FTL_EI_GREEN_COUNT] = E.green_count; ei[FTL_EI_SPARE] = E.green_len;
-        double* ed = P.env_dbl + (size_t)E.env * FTL_ED_COUNT;
+        ei[FTL_EI_ERROR] = E.error; ei[FTL_EI_EPISODES] = E.episodes; ei[FTL_EI_GREEN_COUNT] = E.green_count; ei[FTL_EI_GREEN_LEN] = E.green_len;
+        ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SPARE] = 0;
         ed[FTL_ED_ACC_PENALTY] = E.acc_penalty; ed[FTL_ED_OVERALL_REWARD] = E.overall_reward;
         ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty;
-#pragma unroll
-        for (int b = 0; b < FTL_MAX_BEARS; b++) { ed[FTL_ED_BEAR_POINTS + 2 * b] = E.bear_pt[b][0]; ed[FTL_ED_BEAR_POINTS + 2 * b + 1] = E.bear_pt[b][1]; }
     }
     if (E.lane < P.R) {
         size_t ro = (size_t)E.env * P.R + E.lane;
@@ -325,11 +352,16 @@ __device__ void env_store(EnvCtx& E) {
         int* ri = P.rb_int + ro * FTL_RI_COUNT;
         ri[FTL_RI_X] = E.rb.rx; ri[FTL_RI_Y] = E.rb.ry; ri[FTL_RI_W] = E.rb.rw; ri[FTL_RI_H] = E.rb.rh;
         ri[FTL_RI_ROT_DIR] = E.rb.rot_dir; ri[FTL_RI_DES_ROT_DIR] = E.rb.des_rot_dir; ri[FTL_RI_SPARE0] = 0; ri[FTL_RI_SPARE1] = 0;
+        if (E.lane >= 2) {
+            int b = E.lane - 2;
+            ed[FTL_ED_BEAR_POINTS + 2 * b] = E.rb.tgt_x; ed[FTL_ED_BEAR_POINTS + 2 * b + 1] = E.rb.tgt_y;
+            ei[FTL_EI_DYN_INDEX0 + b] = E.rb.dyn_index;
+        }
     }
 }
 
 // ---- reset(): ENV:494-543 from scenario `scen` ----------------------------------------------------------------
-__device__ void env_reset(EnvCtx& E, int scen) {
+__device__ __forceinline__ void env_reset(EnvCtx& E, int scen) {
     const FtlDevParams& P = E.P;
     const ftl_config& c = P.cfg;
     E.scen = scen;
@@ -340,9 +372,9 @@ __device__ void env_reset(EnvCtx& E, int scen) {
     E.rb.speed = 0; E.rb.rot_speed = 0; E.rb.des_speed = 0; E.rb.des_rot_speed = 0; E.rb.rot_dir = 0; E.rb.des_rot_dir = 0;
     const int* rr = P.scen.robot_rect + so * 4;
     E.rb.rx = rr[0]; E.rb.ry = rr[1]; E.rb.rw = rr[2]; E.rb.rh = rr[3];
-    set_robot_limits(E);
     __syncthreads();
-    stage_static(E);
+    stage_static(E.s_static, P, scen, E.lane);
+    E.route_len = P.scen.route_len[scen];
     // initial leader_factual_trajectory (ENV:533-539)
     int n0 = P.scen.init_traj_len[scen];
     const float2* src = reinterpret_cast<const float2*>(P.scen.init_traj) + (size_t)scen * c.init_traj_cap;
@@ -352,15 +384,13 @@ __device__ void env_reset(EnvCtx& E, int scen) {
     E.step_count = 0; E.acc_penalty = 0; E.overall_reward = 0;
     E.done = 0; E.crash = 0; E.is_in_box = 0; E.is_on_trace = 0; E.too_close = 0;
     E.cur_target_id = 1; E.leader_finished = 0; E.finish_timer = -1;
-    E.green_count = 0; E.green_len = -1; E.error = 0;
+    E.green_count = 0; E.green_len = -1; E.error = 0; E.scan_ok = 0;
     float lpx = rl_f(E.rb.px, 0), lpy = rl_f(E.rb.py, 0);
     const double* rt = route_ptr(E);
     if (E.route_len == 0) { E.done = 1; E.cur_tx = (double)lpx; E.cur_ty = (double)lpy; }
     else { int id = E.route_len > 1 ? 1 : 0; E.cur_tx = rt[2 * id]; E.cur_ty = rt[2 * id + 1]; }
-#pragma unroll
-    for (int b = 0; b < FTL_MAX_BEARS; b++) {       // ENV:717-718
-        E.bear_pt[b][0] = (double)(lpx - 150.0f); E.bear_pt[b][1] = (double)(lpy - 150.0f); E.dyn_index[b] = 0;
-    }
+    // ENV:717-718: every bear starts from the LAST bear_start_position, (leader - 150, leader - 150) in float32
+    E.rb.tgt_x = (double)(lpx - 150.0f); E.rb.tgt_y = (double)(lpy - 150.0f); E.rb.dyn_index = 0;
     E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0;
     __syncthreads();
 }
@@ -408,7 +438,7 @@ __device__ __forceinline__ int closest_point(const EnvCtx& E, float px, float py
     return bi;
 }
 
-__device__ void frame_step(EnvCtx& E, double& reward, int& i0, int& i1, int& i2) {
+__device__ __forceinline__ void frame_step(EnvCtx& E, const Limits& L, double& reward, int& i0, int& i1, int& i2) {
     const FtlDevParams& P = E.P;
     const ftl_config& c = P.cfg;
     const int lane = E.lane;
@@ -427,50 +457,41 @@ __device__ void frame_step(EnvCtx& E, double& reward, int& i0, int& i1, int& i2)
         if (E.cur_target_id >= E.route_len) E.leader_finished = 1;
         else { const double* rt = route_ptr(E); E.cur_tx = rt[2 * E.cur_target_id]; E.cur_ty = rt[2 * E.cur_target_id + 1]; }
     }
-    // bears: way-point choice (ENV:722-758, 819-837); the point is a function of the leader pose only
+    // bears: way-point choice (ENV:722-758, 819-837), one bear per lane; the point depends on the leader pose only
     double tx = E.cur_tx, ty = E.cur_ty;
-    if (c.n_bears > 0) {
-        double boff = 0.0, blvl = 0.0;
-#pragma unroll
-        for (int b = 0; b < FTL_MAX_BEARS; b++) {
-            if (b < c.n_bears) {
-                float bpx = rl_f(E.rb.px, 2 + b), bpy = rl_f(E.rb.py, 2 + b);
-                bool near = euclid_f64((double)bpx, (double)bpy, E.bear_pt[b][0], E.bear_pt[b][1]) < c.leader_pos_epsilon;
-                double off, lvl;
-                if (c.move_bear_v4 && (b & 1)) {
-                    if (near) E.dyn_index[b] += 1;
-                    if (E.dyn_index[b] > 3) E.dyn_index[b] = 0;
-                    // p1=(150,+140) p2=(150,-140) p3=(250,-160) p4=(250,+160); per-index orders of ENV:742-749
-                    const int order = (b == 1) ? 0x2134 /*p4,p3,p1,p2*/ : 0x4213 /*p3,p1,p2,p4*/;
-                    int p = (order >> (4 * E.dyn_index[b])) & 0xf;
-                    lvl = (p <= 2) ? 150.0 : 250.0;
-                    off = (p == 1) ? 140.0 : (p == 2) ? -140.0 : (p == 3) ? -160.0 : 160.0;
-                } else {
-                    if (near) { E.dyn_index[b] += 1; if (E.dyn_index[b] > 1) E.dyn_index[b] = 0; }
-                    lvl = 100.0 * (b + 1);
-                    off = (E.dyn_index[b] == 0) ? -130.0 : 130.0;
-                }
-                if (lane == 2 + b) { boff = off; blvl = lvl; }
-            }
+    const bool is_bear = lane >= 2 && lane < P.R;
+    if (c.n_bears > 0 && is_bear) {
+        const int b = lane - 2;
+        bool near = euclid_f64((double)E.rb.px, (double)E.rb.py, E.rb.tgt_x, E.rb.tgt_y) < c.leader_pos_epsilon;
+        double off, lvl;
+        if (c.move_bear_v4 && (b & 1)) {
+            if (near) E.rb.dyn_index += 1;
+            if (E.rb.dyn_index > 3) E.rb.dyn_index = 0;
+            // p1=(150,+140) p2=(150,-140) p3=(250,-160) p4=(250,+160); per-index orders of ENV:742-749
+            const int order = (b == 1) ? 0x2134 /*p4,p3,p1,p2*/ : 0x4213 /*p3,p1,p2,p4*/;
+            int p = (order >> (4 * E.rb.dyn_index)) & 0xf;
+            lvl = (p <= 2) ? 150.0 : 250.0;
+            off = (p == 1) ? 140.0 : (p == 2) ? -140.0 : (p == 3) ? -160.0 : 160.0;
+        } else {
+            if (near) { E.rb.dyn_index += 1; if (E.rb.dyn_index > 1) E.rb.dyn_index = 0; }
+            lvl = 100.0 * (b + 1);
+            off = (E.rb.dyn_index == 0) ? -130.0 : 130.0;
         }
-        bool is_bear = lane >= 2 && lane < P.R;
-        if (is_bear) {                  // rotateVector([lvl,0], leader.direction + off), misc.py:47-53
-            double s, co;
-            sincos((ldir0 + boff) * kDeg2Rad, &s, &co);
-            tx = (double)lpx0 + co * blvl; ty = (double)lpy0 + s * blvl;
-        }
-#pragma unroll
-        for (int b = 0; b < FTL_MAX_BEARS; b++)
-            if (b < c.n_bears) { E.bear_pt[b][0] = rl_d(tx, 2 + b); E.bear_pt[b][1] = rl_d(ty, 2 + b); }
+        double s, co;                    // rotateVector([lvl,0], leader.direction + off), misc.py:47-53
+        sincos_bounded((ldir0 + off) * kDeg2Rad, s, co);
+        tx = (double)lpx0 + co * lvl; ty = (double)lpy0 + s * lvl;
+        E.rb.tgt_x = tx; E.rb.tgt_y = ty;
     }
     // steering of leader + bears (classes.py:184-215); the follower keeps the commands of step()
-    bool steers = (lane == 0 && !E.leader_finished) || (lane >= 2 && lane < P.R);
-    if (steers) steer_to_point(E.rb, tx, ty, lane == 0, E.rb.max_speed + 0);
-    if (lane == 0 && E.leader_finished) { command_forward(E.rb, 0); command_turn(E.rb, 0, 0); i2 = FTL_LEADER_FINISHED; }  // ENV:1062-1065
-    i2 = rl_i(i2, 0);
+    bool steers = (lane == 0 && !E.leader_finished) || is_bear;
+    if (steers) steer_to_point(E.rb, L, tx, ty, lane == 0, L.max_speed + 0);
+    if (E.leader_finished) {                                   // ENV:1062-1065
+        if (lane == 0) { command_forward(E.rb, L, 0); command_turn(E.rb, L, 0, 0); }
+        i2 = FTL_LEADER_FINISHED;
+    }
     // move(): every robot of the env in lock-step (the finished leader only receives commands)
     bool moves = (lane < P.R) && !(lane == 0 && E.leader_finished);
-    robot_move(E.rb, moves);
+    robot_move(E.rb, L, moves);
 
     const float fpx = rl_f(E.rb.px, 1), fpy = rl_f(E.rb.py, 1);
     const int frx = rl_i(E.rb.rx, 1), fry = rl_i(E.rb.ry, 1), frw = rl_i(E.rb.rw, 1), frh = rl_i(E.rb.rh, 1);
@@ -553,15 +574,15 @@ __device__ void frame_step(EnvCtx& E, double& reward, int& i0, int& i1, int& i2)
 }
 
 // ---- LeaderPositionsTracker_v2.scan (sensors.py:243-327) --------------------------------------------------------
-__device__ __forceinline__ double* hist_slot(const EnvCtx& E, int abs_idx) {
-    return E.P.hist + ((size_t)E.env * E.P.cfg.corr_cap + (abs_idx % E.P.cfg.corr_cap)) * 2;
+__device__ __forceinline__ double* hist_slot(const FtlDevParams& P, int env, int abs_idx) {
+    return P.hist + ((size_t)env * P.cfg.corr_cap + (abs_idx % P.cfg.corr_cap)) * 2;
 }
-__device__ __forceinline__ double* corr_slot(const EnvCtx& E, int abs_idx) {
-    return E.P.corr + ((size_t)E.env * E.P.cfg.corr_cap + (abs_idx % E.P.cfg.corr_cap)) * 4;
+__device__ __forceinline__ double* corr_slot(const FtlDevParams& P, int env, int abs_idx) {
+    return P.corr + ((size_t)env * P.cfg.corr_cap + (abs_idx % P.cfg.corr_cap)) * 4;
 }
 // sensors.py:302-317: border pair from hist[i1]-hist[i0] anchored at hist[ia] (absolute indices), appended at corr index `at`
-__device__ void border_pair(EnvCtx& E, int i1, int i0, int ia, int at) {
-    const double* p1 = hist_slot(E, i1); const double* p0 = hist_slot(E, i0); const double* a = hist_slot(E, ia);
+__device__ __forceinline__ void border_pair(EnvCtx& E, int i1, int i0, int ia, int at) {
+    const double* p1 = hist_slot(E.P, E.env, i1); const double* p0 = hist_slot(E.P, E.env, i0); const double* a = hist_slot(E.P, E.env, ia);
     double vx, vy;
     if (i1 < E.seed_end || i0 < E.seed_end) {
         vx = p1[0] - p0[0]; vy = p1[1] - p0[1];
@@ -578,18 +599,18 @@ __device__ void border_pair(EnvCtx& E, int i1, int i0, int ia, int at) {
     const double c90 = 6.123233995736766e-17, s90 = 1.0, cm90 = 6.123233995736766e-17, sm90 = -1.0;
     double r0 = (c90 * vx + (-s90) * vy) + a[0], r1 = (s90 * vx + c90 * vy) + a[1];
     double l0 = (cm90 * vx + (-sm90) * vy) + a[0], l1 = (sm90 * vx + cm90 * vy) + a[1];
-    if (E.lane == 0) { double* q = corr_slot(E, at); q[0] = r0; q[1] = r1; q[2] = l0; q[3] = l1; }
+    if (E.lane == 0) { double* q = corr_slot(E.P, E.env, at); q[0] = r0; q[1] = r1; q[2] = l0; q[3] = l1; }
 }
 // np.sum(np.linalg.norm(diff(hist))) over the window [lo, hi) (sensors.py:288-290)
-__device__ double hist_path_length(EnvCtx& E, int lo, int hi) {
+__device__ __forceinline__ double hist_path_length(EnvCtx& E, int lo, int hi) {
     int m = hi - lo;
     if (m < 2) return 0.0;
     bool any64 = lo < E.seed_end;
-    double* sd = reinterpret_cast<double*>(E.s_d);   // FTL_DCHUNK floats = 128 doubles; longer windows go chunk-free via global? no: validated cap
     __syncthreads();
     if (any64) {
+        double* sd = reinterpret_cast<double*>(E.s_d);
         for (int i = E.lane; i < m - 1; i += FTL_WAVE) {
-            const double* p = hist_slot(E, lo + i); const double* q = hist_slot(E, lo + i + 1);
+            const double* p = hist_slot(E.P, E.env, lo + i); const double* q = hist_slot(E.P, E.env, lo + i + 1);
             double dx = p[0] - q[0], dy = p[1] - q[1];
             sd[i] = sqrt(dx * dx + dy * dy);
         }
@@ -598,7 +619,7 @@ __device__ double hist_path_length(EnvCtx& E, int lo, int hi) {
     }
     float* sf = E.s_d;
     for (int i = E.lane; i < m - 1; i += FTL_WAVE) {
-        const double* p = hist_slot(E, lo + i); const double* q = hist_slot(E, lo + i + 1);
+        const double* p = hist_slot(E.P, E.env, lo + i); const double* q = hist_slot(E.P, E.env, lo + i + 1);
         float dx = (float)p[0] - (float)q[0], dy = (float)p[1] - (float)q[1];
         sf[i] = sqrtf(dx * dx + dy * dy);
     }
@@ -606,13 +627,13 @@ __device__ double hist_path_length(EnvCtx& E, int lo, int hi) {
     return (double)pairwise_sum<float>(sf, m - 1);
 }
 
-__device__ void tracker_scan(EnvCtx& E) {
+__device__ __forceinline__ void tracker_scan(EnvCtx& E) {
     const ftl_config& c = E.P.cfg;
     const float lpx = rl_f(E.rb.px, 0), lpy = rl_f(E.rb.py, 0);
     if (E.trk_counter % c.tracker_saving_period == 0) {
         int len = E.corr_hi - E.corr_lo;
         if (len > 0) {
-            const double* last = hist_slot(E, E.corr_hi - 1);
+            const double* last = hist_slot(E.P, E.env, E.corr_hi - 1);
             if (last[0] == (double)lpx && last[1] == (double)lpy) return;     // sensors.py:247-251 (no counter increment)
         }
         bool first = (len == 0 && E.trk_counter == 0);
@@ -623,7 +644,7 @@ __device__ void tracker_scan(EnvCtx& E) {
             int n;
             if (c.tracker_start_behind) {                     // sensors.py:257-272 (float64 seed points)
                 double s, co;
-                sincos(angle_correction(fdir + 180.0) * kDeg2Rad, &s, &co);
+                sincos_bounded(angle_correction(fdir + 180.0) * kDeg2Rad, s, co);
                 double sx = 50 * co + (double)fpx, sy = 50 * s + (double)fpy;
                 double dist = euclid_f64(sx, sy, (double)lpx, (double)lpy);
                 n = (int)(dist / ((double)(c.tracker_saving_period * 5) * lmax));
@@ -633,7 +654,7 @@ __device__ void tracker_scan(EnvCtx& E) {
                     double x = (stepx == 0) ? ((double)i / (n - 1)) * ((double)lpx - sx) + sx : (double)i * stepx + sx;
                     double y = (stepy == 0) ? ((double)i / (n - 1)) * ((double)lpy - sy) + sy : (double)i * stepy + sy;
                     if (i == n - 1) { x = (double)lpx; y = (double)lpy; }
-                    double* h = hist_slot(E, i); h[0] = x; h[1] = y;
+                    double* h = hist_slot(E.P, E.env, i); h[0] = x; h[1] = y;
                 }
                 E.seed_end = n;
             } else {                                          // sensors.py:275-284 (np.linspace(f32,f32) is float32)
@@ -645,7 +666,7 @@ __device__ void tracker_scan(EnvCtx& E) {
                     float x = (stepx == 0) ? ((float)i / (float)(n - 1)) * (lpx - fpx) + fpx : (float)i * stepx + fpx;
                     float y = (stepy == 0) ? ((float)i / (float)(n - 1)) * (lpy - fpy) + fpy : (float)i * stepy + fpy;
                     if (i == n - 1) { x = lpx; y = lpy; }
-                    double* h = hist_slot(E, i); h[0] = (double)x; h[1] = (double)y;
+                    double* h = hist_slot(E.P, E.env, i); h[0] = (double)x; h[1] = (double)y;
                 }
                 E.seed_end = 0;
             }
@@ -657,10 +678,9 @@ __device__ void tracker_scan(EnvCtx& E) {
             int nsnap = E.snap_count < E.P.hmax ? E.snap_count : E.P.hmax;
             for (int j = 0; j < nsnap; j++) { int l0 = sw[4 * j], l1 = sw[4 * j + 2]; oldest = min(oldest, min(l0, l1)); }
             if (E.corr_hi + 1 - oldest > c.corr_cap) { E.error |= FTL_ERR_CORR_OVERFLOW; E.trk_counter += 1; return; }
-            if (E.lane == 0) { double* h = hist_slot(E, E.corr_hi); h[0] = (double)lpx; h[1] = (double)lpy; }
+            if (E.lane == 0) { double* h = hist_slot(E.P, E.env, E.corr_hi); h[0] = (double)lpx; h[1] = (double)lpy; }
             E.corr_hi += 1;
         }
-        __threadfence_block();
         __syncthreads();
         // sensors.py:288-297: drop the oldest points (and border pairs) while the polyline is longer than corridor_length
         double path = hist_path_length(E, E.corr_lo, E.corr_hi);
@@ -677,22 +697,71 @@ __device__ void tracker_scan(EnvCtx& E) {
             }
             border_pair(E, E.corr_hi - 1, E.corr_hi - 2, E.corr_hi - 2, E.corr_hi - 1);
         }
-        __threadfence_block();
         __syncthreads();
     }
     E.trk_counter += 1;
 }
 
-// ---- LeaderCorridor_Prev_lasers_v2.scan (sensors.py:883-962) for every ray sensor of the env ---------------------
+// classes.py:255-288 minus the ray casts: both tracker scans, the bookkeeping of the ray sensors' history push
+// (sensors.py:893-897: a sensor scans -- and pushes a snapshot -- only while len(corridor) > 1) and the error flag the
+// reference would have raised.  The rays themselves are cast by ftl_rays_kernel from the snapshot ring.
+__device__ __forceinline__ void sensors_bookkeeping(EnvCtx& E) {
+    const FtlDevParams& P = E.P;
+    const ftl_config& c = P.cfg;
+    if (!c.has_tracker) { E.scan_ok = 0; return; }
+    int groups = 0;       // bit g: some ray sensor is scanned in group g (0 = before the tracker's 2nd scan, 1 = after)
+    for (int k = 0; k < c.n_lasers; k++) groups |= 1 << (c.lasers[k].after_tracker ? 1 : 0);
+    int ok = 0, w0lo = 0, w0hi = 0;
+#pragma nounroll
+    for (int g = 0; g < 2; g++) {
+        tracker_scan(E);
+        if ((groups >> g) & 1) {
+            if (E.corr_hi - E.corr_lo > 1) ok |= 1 << g;
+            else E.error |= FTL_ERR_EMPTY_CORRIDOR;
+        }
+        if (g == 0) { w0lo = E.corr_lo; w0hi = E.corr_hi; }
+    }
+    E.scan_ok = ok;
+    if (ok) {             // one snapshot per step: dynamic rects + the corridor window each group saw
+        int slot = E.snap_count % P.hmax;
+        int4* sr = reinterpret_cast<int4*>(P.snap_rects) + ((size_t)E.env * P.hmax + slot) * (P.R - 1);
+        if (E.lane < P.R && E.lane != 1) sr[E.lane == 0 ? 0 : E.lane - 1] = make_int4(E.rb.rx, E.rb.ry, E.rb.rw, E.rb.rh);
+        if (E.lane == 0) {
+            int* sw = P.snap_win + ((size_t)E.env * P.hmax + slot) * 4;
+            bool g0 = ok & 1;
+            sw[0] = g0 ? w0lo : E.corr_lo; sw[1] = g0 ? w0hi : E.corr_hi; sw[2] = E.corr_lo; sw[3] = E.corr_hi;
+        }
+        E.snap_count += 1;
+    }
+}
+
+// ENV:1789-1810
+__device__ __forceinline__ void write_obs(EnvCtx& E) {
+    float lp[5], fp[5];
+    lp[0] = rl_f(E.rb.px, 0); lp[1] = rl_f(E.rb.py, 0); lp[2] = (float)rl_d(E.rb.speed, 0); lp[3] = (float)rl_d(E.rb.direction, 0); lp[4] = (float)rl_d(E.rb.rot_speed, 0);
+    fp[0] = rl_f(E.rb.px, 1); fp[1] = rl_f(E.rb.py, 1); fp[2] = (float)rl_d(E.rb.speed, 1); fp[3] = (float)rl_d(E.rb.direction, 1); fp[4] = (float)rl_d(E.rb.rot_speed, 1);
+    if (E.lane == 0) {
+        float* o = E.C.out.obs_num + (size_t)E.env * FTL_OBS_NUM;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { o[i] = lp[i]; o[5 + i] = fp[i]; }
+        double tx = E.cur_tx, ty = E.cur_ty;
+        if (E.route_len > 1) {
+            const double* rt = route_ptr(E);
+            if (tx == rt[2 * (E.route_len - 1)] && ty == rt[2 * (E.route_len - 1) + 1]) { tx = rt[2 * (E.route_len - 2)]; ty = rt[2 * (E.route_len - 2) + 1]; }
+        }
+        E.C.out.target[2 * (size_t)E.env] = tx; E.C.out.target[2 * (size_t)E.env + 1] = ty;
+    }
+}
+
+// ---- LeaderCorridor_Prev_lasers_v2.scan (sensors.py:883-962): the rays ----------------------------------------------
 struct Ray {
     double ex, ey;        // ray end, float64 (sensors.py:888-891)
     double best[FTL_HMAX];
     int sensor;           // -1 = idle lane
-    int first_snap;       // rows below this are "history not filled yet"
 };
 
 // One obstacle segment A->B (float32, as stored by np.array(..., dtype=np.float32), sensors.py:672) against this lane's ray.
-// `snapmask` = history snapshots that contain the segment, `sensmask` = ray sensors that react to it.
+// `snapmask` = history snapshots (by age) that contain the segment, `sensmask` = ray sensors that react to it.
 __device__ __forceinline__ void test_segment(Ray& ry, float cx, float cy, float ax, float ay, float bx, float by,
                                              unsigned snapmask, unsigned sensmask) {
     if (ry.sensor < 0 || !((sensmask >> ry.sensor) & 1u)) return;
@@ -728,189 +797,10 @@ __device__ __forceinline__ void test_rect(Ray& ry, float cx, float cy, int4 q, u
     test_segment(ry, cx, cy, l, b, l, t, snapmask, sensmask);   // bottomleft-topleft
 }
 
-// push the snapshot of this scan (sensors.py:896-897): dynamic rects + corridor windows; `which` = 0 for sensors
-// scanned before the tracker's second scan of the step, 1 after it
-__device__ void snapshot_push(EnvCtx& E, int which, bool is_new) {
-    const FtlDevParams& P = E.P;
-    int slot = (is_new ? E.snap_count : E.snap_count - 1) % P.hmax;
-    int* sw = P.snap_win + ((size_t)E.env * P.hmax + slot) * 4;
-    if (is_new) {
-        int4* sr = reinterpret_cast<int4*>(P.snap_rects) + ((size_t)E.env * P.hmax + slot) * (P.R - 1);
-        if (E.lane < P.R && E.lane != 1) sr[E.lane == 0 ? 0 : E.lane - 1] = make_int4(E.rb.rx, E.rb.ry, E.rb.rw, E.rb.rh);
-        if (E.lane == 0) { sw[0] = E.corr_lo; sw[1] = E.corr_hi; sw[2] = E.corr_lo; sw[3] = E.corr_hi; }
-        E.snap_count += 1;
-    } else if (E.lane == 0) { sw[2 * which] = E.corr_lo; sw[2 * which + 1] = E.corr_hi; }
-}
-
-// scan all ray sensors with after_tracker == which
-__device__ void lasers_scan(EnvCtx& E, int which, bool& pushed) {
-    const FtlDevParams& P = E.P;
-    const ftl_config& c = P.cfg;
-    bool any = false;
-    for (int k = 0; k < c.n_lasers; k++) any |= (c.lasers[k].after_tracker == which);
-    if (!any) return;
-    const float cx = rl_f(E.rb.px, 1), cy = rl_f(E.rb.py, 1);
-    const double fdir = rl_d(E.rb.direction, 1);
-    float* out_base = E.C.out.lasers + (size_t)E.env * P.lasers_len;
-    if (E.corr_hi - E.corr_lo <= 1) {      // sensors.py:893/962: the reference raises UnboundLocalError here
-        E.error |= FTL_ERR_EMPTY_CORRIDOR;
-        for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which)
-            for (int i = E.lane; i < c.lasers[k].history * c.lasers[k].count; i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = (float)c.lasers[k].length;
-        return;
-    }
-    snapshot_push(E, which, !pushed);
-    pushed = true;
-    __threadfence_block();
-    __syncthreads();
-    // ---- stage the history in LDS: dynamic rects of the last hmax snapshots + the f32 corridor ring --------------
-    const int hmax = P.hmax;
-    const int nsnap = E.snap_count < hmax ? E.snap_count : hmax;       // valid snapshots, newest = snap_count-1
-    {
-        const int4* sr = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)E.env * hmax * (P.R - 1);
-        for (int i = E.lane; i < hmax * (P.R - 1); i += FTL_WAVE) E.s_snaprect[i] = sr[i];
-    }
-    // corridor windows of the valid snapshots as this group of sensors saw them; age a = 0 newest
-    int win_lo[FTL_HMAX], win_hi[FTL_HMAX];
-    int umin = 0x7fffffff, umax = 0;
-    {
-        const int* sw = P.snap_win + (size_t)E.env * hmax * 4;
-#pragma unroll
-        for (int a = 0; a < FTL_HMAX; a++) {
-            win_lo[a] = 0; win_hi[a] = 0;
-            if (a < nsnap) {
-                int slot = (E.snap_count - 1 - a) % hmax;
-                win_lo[a] = sw[4 * slot + 2 * which]; win_hi[a] = sw[4 * slot + 2 * which + 1];
-                umin = min(umin, win_lo[a]); umax = max(umax, win_hi[a]);
-            }
-        }
-    }
-    for (int p = umin + E.lane; p < umax; p += FTL_WAVE) {
-        const double* q = corr_slot(E, p);
-        E.s_corr[p % c.corr_cap] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
-    }
-    __syncthreads();
-
-    // ---- rays: one per lane, passes of 64 -----------------------------------------------------------------------
-    int total = 0; float lmax = 0.0f;
-    for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) { total += c.lasers[k].count; lmax = fmaxf(lmax, (float)c.lasers[k].length); }
-    const float reach = lmax + 2.0f;            // culling radius: a segment entirely outside cannot meet any ray
-    const float bx0 = cx - reach, bx1 = cx + reach, by0 = cy - reach, by1 = cy + reach;
-    for (int base = 0; base < total; base += FTL_WAVE) {
-        Ray ry; ry.sensor = -1; ry.first_snap = 0; ry.ex = 0; ry.ey = 0;
-        int ray_in_sensor = 0; double len = 0; int H = 0, N = 0, ooff = 0;
-        {
-            int q = base + E.lane, accn = 0;
-            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) {
-                if (q >= accn && q < accn + c.lasers[k].count) {
-                    ry.sensor = k; ray_in_sensor = q - accn; len = c.lasers[k].length; H = c.lasers[k].history; N = c.lasers[k].count; ooff = c.lasers[k].out_offset;
-                    double period = 360.0 / (double)N;
-                    double s, co;
-                    sincos(((fdir + c.lasers[k].angle_offset) + ray_in_sensor * period) * kDeg2Rad, &s, &co);
-                    ry.ex = (double)cx + co * len; ry.ey = (double)cy + s * len;
-                }
-                accn += c.lasers[k].count;
-            }
-        }
-        // reading when nothing is hit: |end - origin| (sensors.py:925-930)
-        double qx0 = ry.ex - (double)cx, qy0 = ry.ey - (double)cy;
-        const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
-#pragma unroll
-        for (int j = 0; j < FTL_HMAX; j++) ry.best[j] = 1.0e300;
-        // sensor masks by obstacle class (sensors.py:651-660): statics+leader for True/"all"/"static", bears for True/"all"/"dynamic"
-        unsigned m_static = 0, m_dyn = 0, m_corr = 0, m_green = 0;
-        for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) {
-            int ro = c.lasers[k].react_obstacles;
-            if (ro == 1 || ro == 2) m_static |= 1u << k;
-            if (ro == 1 || ro == 3) m_dyn |= 1u << k;
-            if (c.lasers[k].react_corridor) m_corr |= 1u << k;
-            if (c.lasers[k].react_green) m_green |= 1u << k;
-        }
-        const unsigned all_snaps = (nsnap >= 32) ? 0xffffffffu : ((1u << nsnap) - 1u);   // bit a = age a
-        // static rects: identical in every snapshot
-        if (m_static) for (int s = 0; s < c.n_static; s++) {
-            int4 q = E.s_static[s];
-            if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) continue;
-            test_rect(ry, cx, cy, q, all_snaps, m_static);
-        }
-        // dynamic rects per snapshot (leader counts as a static-class object, it sits in game_object_list)
-        for (int a = 0; a < nsnap; a++) {
-            int slot = (E.snap_count - 1 - a) % hmax;
-            for (int o = 0; o < P.R - 1; o++) {
-                unsigned sm = (o == 0) ? m_static : m_dyn;
-                if (!sm) continue;
-                int4 q = E.s_snaprect[slot * (P.R - 1) + o];
-                if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) continue;
-                test_rect(ry, cx, cy, q, 1u << a, sm);
-            }
-        }
-        // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
-        if (m_corr) for (int p = umin; p + 1 < umax; p++) {
-            unsigned sm = 0;
-#pragma unroll
-            for (int a = 0; a < FTL_HMAX; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
-            if (!sm) continue;
-            float4 u = E.s_corr[p % c.corr_cap], v = E.s_corr[(p + 1) % c.corr_cap];
-            if (!(fmaxf(u.x, v.x) < bx0 || fminf(u.x, v.x) > bx1 || fmaxf(u.y, v.y) < by0 || fminf(u.y, v.y) > by1))
-                test_segment(ry, cx, cy, u.x, u.y, v.x, v.y, sm, m_corr);      // right border
-            if (!(fmaxf(u.z, v.z) < bx0 || fminf(u.z, v.z) > bx1 || fmaxf(u.w, v.w) < by0 || fminf(u.w, v.w) > by1))
-                test_segment(ry, cx, cy, u.z, u.w, v.z, v.w, sm, m_corr);      // left border
-        }
-        // green-zone end caps of every snapshot (sensors.py:648-650)
-        if (m_green) {
-#pragma unroll
-            for (int a = 0; a < FTL_HMAX; a++) if (a < nsnap) {
-                float4 u = E.s_corr[win_lo[a] % c.corr_cap], v = E.s_corr[(win_hi[a] - 1) % c.corr_cap];
-                test_segment(ry, cx, cy, u.x, u.y, u.z, u.w, 1u << a, m_green);
-                test_segment(ry, cx, cy, v.x, v.y, v.z, v.w, 1u << a, m_green);
-            }
-        }
-        // rows: oldest first, newest last (sensors.py:896-901); rows older than the first scan read `miss`
-        if (ry.sensor >= 0) {
-#pragma unroll
-            for (int a = 0; a < FTL_HMAX; a++) {
-                if (a < H) {
-                    int row = H - 1 - a;
-                    double v = (a < nsnap && ry.best[a] < 1.0e299) ? ry.best[a] : miss;
-                    out_base[ooff + row * N + ray_in_sensor] = (float)v;
-                }
-            }
-        }
-    }
-}
-
-// classes.py:255-288
-__device__ void use_sensors(EnvCtx& E) {
-    const ftl_config& c = E.P.cfg;
-    bool pushed = false;
-    if (c.has_tracker) tracker_scan(E);
-    lasers_scan(E, 0, pushed);
-    if (c.has_tracker) tracker_scan(E);
-    lasers_scan(E, 1, pushed);
-}
-
-// ENV:1789-1810
-__device__ void write_obs(EnvCtx& E) {
-    const FtlDevParams& P = E.P;
-    float lp[5], fp[5];
-    lp[0] = rl_f(E.rb.px, 0); lp[1] = rl_f(E.rb.py, 0); lp[2] = (float)rl_d(E.rb.speed, 0); lp[3] = (float)rl_d(E.rb.direction, 0); lp[4] = (float)rl_d(E.rb.rot_speed, 0);
-    fp[0] = rl_f(E.rb.px, 1); fp[1] = rl_f(E.rb.py, 1); fp[2] = (float)rl_d(E.rb.speed, 1); fp[3] = (float)rl_d(E.rb.direction, 1); fp[4] = (float)rl_d(E.rb.rot_speed, 1);
-    if (E.lane == 0) {
-        float* o = E.C.out.obs_num + (size_t)E.env * FTL_OBS_NUM;
-#pragma unroll
-        for (int i = 0; i < 5; i++) { o[i] = lp[i]; o[5 + i] = fp[i]; }
-        double tx = E.cur_tx, ty = E.cur_ty;
-        if (E.route_len > 1) {
-            const double* rt = route_ptr(E);
-            if (tx == rt[2 * (E.route_len - 1)] && ty == rt[2 * (E.route_len - 1) + 1]) { tx = rt[2 * (E.route_len - 2)]; ty = rt[2 * (E.route_len - 2) + 1]; }
-        }
-        E.C.out.target[2 * (size_t)E.env] = tx; E.C.out.target[2 * (size_t)E.env + 1] = ty;
-    }
-}
-
 }  // namespace ftl
 
-// ---------------------------------------------------------------- the kernel
-extern "C" __global__ void __launch_bounds__(FTL_WAVE) ftl_env_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
+// ---------------------------------------------------------------- kernel 1: frames + tracker + observation
+extern "C" __global__ void __launch_bounds__(FTL_WAVE) ftl_frames_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
     using namespace ftl;
     const FtlDevParams& P = *Pp;
@@ -918,53 +808,194 @@ extern "C" __global__ void __launch_bounds__(FTL_WAVE) ftl_env_kernel(const FtlD
     if (env >= P.n_envs) return;
     EnvCtx E(P, C);
     E.env = env; E.lane = threadIdx.x;
-    {   // LDS carve-up (16-byte aligned pieces)
-        unsigned char* p = lds;
-        E.s_static = reinterpret_cast<int4*>(p); p += (size_t)((P.cfg.n_static + 3) & ~3) * 16 + 16;
-        E.s_d = reinterpret_cast<float*>(p); p += FTL_DCHUNK * 4 * 4;    // 4 KB: 256 floats / 512 doubles scratch
-        E.s_snaprect = reinterpret_cast<int4*>(p); p += (size_t)P.hmax * (P.R - 1) * 16;
-        E.s_corr = reinterpret_cast<float4*>(p);
-    }
+    E.s_static = reinterpret_cast<int4*>(lds);
+    E.s_d = reinterpret_cast<float*>(lds + (size_t)((P.cfg.n_static + 3) & ~3) * 16 + 16);
+    E.scan_ok = 0;
     if (C.mode == 1) {                                   // reset(): ENV:434-543
         if (C.mask && !C.mask[env]) return;
         E.episodes = P.env_int[(size_t)env * FTL_EI_COUNT + FTL_EI_EPISODES];
         env_reset(E, C.scen_idx[env]);
-        use_sensors(E);
-        write_obs(E);
         if (E.lane == 0) {
             C.out.reward[env] = 0.0; C.out.done[env] = (uint8_t)E.done;
             C.out.status[3 * (size_t)env] = 0; C.out.status[3 * (size_t)env + 1] = 0; C.out.status[3 * (size_t)env + 2] = 0;
         }
-        env_store(E);
-        return;
-    }
-    // step(action): ENV:908-945
-    env_load(E);
-    __syncthreads();
-    {
-        double a0 = C.action[2 * (size_t)env], a1 = C.action[2 * (size_t)env + 1];
-        if (E.lane == 1) {
-            command_forward(E.rb, a0);                                   // ENV:927
-            if (a1 < 0) command_turn(E.rb, fabs(a1), -1);                // ENV:928-933
-            else if (a1 > 0) command_turn(E.rb, a1, 1);
-            else command_turn(E.rb, 0, 0);
+    } else {                                             // step(action): ENV:908-945
+        env_load(E);
+        __syncthreads();
+        const Limits L = lane_limits(P.cfg, E.lane);
+        {
+            double a0 = C.action[2 * (size_t)env], a1 = C.action[2 * (size_t)env + 1];
+            if (E.lane == 1) {
+                command_forward(E.rb, L, a0);                                   // ENV:927
+                if (a1 < 0) command_turn(E.rb, L, fabs(a1), -1);                // ENV:928-933
+                else if (a1 > 0) command_turn(E.rb, L, a1, 1);
+                else command_turn(E.rb, L, 0, 0);
+            }
+        }
+        double reward = 0; int i0 = 0, i1 = 0, i2 = 0;
+#pragma nounroll
+        for (int f = 0; f < P.cfg.frames_per_step; f++) frame_step(E, L, reward, i0, i1, i2);   // ENV:935-936
+        if (E.lane == 0) {
+            C.out.reward[env] = reward; C.out.done[env] = (uint8_t)E.done;
+            C.out.status[3 * (size_t)env] = (uint8_t)i0; C.out.status[3 * (size_t)env + 1] = (uint8_t)i1; C.out.status[3 * (size_t)env + 2] = (uint8_t)i2;
+        }
+        if (E.done && (C.flags & FTL_STEP_AUTO_RESET)) {
+            // vector-env convention: terminal reward/done/status are kept, the observation is the first one of the
+            // next episode (the terminal sensor scan would be discarded, so it is not run)
+            E.episodes += 1;
+            int next = (E.scen + P.n_envs) % P.scen.n_scenarios;
+            __syncthreads();
+            env_reset(E, next);
         }
     }
-    double reward = 0; int i0 = 0, i1 = 0, i2 = 0;
-    for (int f = 0; f < P.cfg.frames_per_step; f++) frame_step(E, reward, i0, i1, i2);   // ENV:935-936
-    use_sensors(E);                                                      // ENV:937
-    if (E.lane == 0) {
-        C.out.reward[env] = reward; C.out.done[env] = (uint8_t)E.done;
-        C.out.status[3 * (size_t)env] = (uint8_t)i0; C.out.status[3 * (size_t)env + 1] = (uint8_t)i1; C.out.status[3 * (size_t)env + 2] = (uint8_t)i2;
-    }
-    if (E.done && (C.flags & FTL_STEP_AUTO_RESET)) {
-        // vector-env convention: terminal reward/done/status are kept, the observation is the new episode's first
-        E.episodes += 1;
-        int next = (E.scen + P.n_envs) % P.scen.n_scenarios;
-        __syncthreads();
-        env_reset(E, next);
-        use_sensors(E);
-    }
-    write_obs(E);
+    sensors_bookkeeping(E);                              // ENV:937 / ENV:541 (tracker part of use_sensors)
+    write_obs(E);                                        // ENV:938
     env_store(E);
+}
+
+// ---------------------------------------------------------------- kernel 2: the ray casts
+extern "C" __global__ void __launch_bounds__(FTL_WAVE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    using namespace ftl;
+    const FtlDevParams& P = *Pp;
+    const ftl_config& c = P.cfg;
+    const int env = blockIdx.x;
+    if (env >= P.n_envs) return;
+    if (C.mode == 1 && C.mask && !C.mask[env]) return;
+    const int lane = threadIdx.x;
+    const int hmax = P.hmax;
+    // LDS: static rects | snapshot rects | f32 corridor ring
+    int4* s_static = reinterpret_cast<int4*>(lds);
+    int4* s_snaprect = reinterpret_cast<int4*>(lds + (size_t)((c.n_static + 3) & ~3) * 16 + 16);
+    float4* s_corr = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(s_snaprect) + (size_t)hmax * (P.R - 1) * 16);
+
+    const int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
+    const int scen = ei[FTL_EI_SCEN], snap_count = ei[FTL_EI_SNAP_COUNT], scan_ok = ei[FTL_EI_SCAN_OK];
+    const size_t fo = (size_t)env * P.R + 1;            // follower
+    const float cx = P.rb_pos[2 * fo], cy = P.rb_pos[2 * fo + 1];
+    const double fdir = P.rb_dbl[fo * FTL_RD_COUNT + FTL_RD_DIRECTION];
+    float* out_base = C.out.lasers + (size_t)env * P.lasers_len;
+
+    stage_static(s_static, P, scen, lane);
+    {
+        const int4* sr = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)env * hmax * (P.R - 1);
+        for (int i = lane; i < hmax * (P.R - 1); i += FTL_WAVE) s_snaprect[i] = sr[i];
+    }
+    const int nsnap = snap_count < hmax ? snap_count : hmax;       // valid snapshots, newest = snap_count-1
+
+#pragma nounroll
+    for (int which = 0; which < 2; which++) {
+        int total = 0; float lmax = 0.0f;
+        unsigned m_static = 0, m_dyn = 0, m_corr = 0, m_green = 0;
+        for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) {
+            total += c.lasers[k].count; lmax = fmaxf(lmax, (float)c.lasers[k].length);
+            // sensor masks by obstacle class (sensors.py:651-660): statics+leader for True/"all"/"static", bears for True/"all"/"dynamic"
+            int ro = c.lasers[k].react_obstacles;
+            if (ro == 1 || ro == 2) m_static |= 1u << k;
+            if (ro == 1 || ro == 3) m_dyn |= 1u << k;
+            if (c.lasers[k].react_corridor) m_corr |= 1u << k;
+            if (c.lasers[k].react_green) m_green |= 1u << k;
+        }
+        if (total == 0) continue;
+        if (!((scan_ok >> which) & 1)) {       // sensors.py:893/962: the reference raises UnboundLocalError here
+            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which)
+                for (int i = lane; i < c.lasers[k].history * c.lasers[k].count; i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = (float)c.lasers[k].length;
+            continue;
+        }
+        // corridor windows of the valid snapshots as this group of sensors saw them; age a = 0 newest
+        int win_lo[FTL_HMAX], win_hi[FTL_HMAX];
+        int umin = 0x7fffffff, umax = 0;
+        {
+            const int* sw = P.snap_win + (size_t)env * hmax * 4;
+#pragma unroll
+            for (int a = 0; a < FTL_HMAX; a++) {
+                win_lo[a] = 0; win_hi[a] = 0;
+                if (a < nsnap) {
+                    int slot = (snap_count - 1 - a) % hmax;
+                    win_lo[a] = sw[4 * slot + 2 * which]; win_hi[a] = sw[4 * slot + 2 * which + 1];
+                    umin = min(umin, win_lo[a]); umax = max(umax, win_hi[a]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int p = umin + lane; p < umax; p += FTL_WAVE) {
+            const double* q = corr_slot(P, env, p);
+            s_corr[p % c.corr_cap] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+        }
+        __syncthreads();
+
+        const float reach = lmax + 2.0f;            // culling radius: a segment entirely outside cannot meet any ray
+        const float bx0 = cx - reach, bx1 = cx + reach, by0 = cy - reach, by1 = cy + reach;
+        const unsigned all_snaps = (1u << nsnap) - 1u;   // bit a = age a (nsnap <= 8)
+        for (int base = 0; base < total; base += FTL_WAVE) {      // rays: one per lane, passes of 64
+            Ray ry; ry.sensor = -1; ry.ex = 0; ry.ey = 0;
+            int ray_in_sensor = 0, H = 0, N = 0, ooff = 0;
+            {
+                int q = base + lane, accn = 0;
+                for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) {
+                    if (q >= accn && q < accn + c.lasers[k].count) {
+                        ry.sensor = k; ray_in_sensor = q - accn; H = c.lasers[k].history; N = c.lasers[k].count; ooff = c.lasers[k].out_offset;
+                        double len = c.lasers[k].length, period = 360.0 / (double)N, s, co;
+                        sincos_bounded(((fdir + c.lasers[k].angle_offset) + ray_in_sensor * period) * kDeg2Rad, s, co);
+                        ry.ex = (double)cx + co * len; ry.ey = (double)cy + s * len;
+                    }
+                    accn += c.lasers[k].count;
+                }
+            }
+            // reading when nothing is hit: |end - origin| (sensors.py:925-930)
+            double qx0 = ry.ex - (double)cx, qy0 = ry.ey - (double)cy;
+            const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
+#pragma unroll
+            for (int j = 0; j < FTL_HMAX; j++) ry.best[j] = 1.0e300;
+            // static rects: identical in every snapshot
+            if (m_static) for (int s = 0; s < c.n_static; s++) {
+                int4 q = s_static[s];
+                if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) continue;
+                test_rect(ry, cx, cy, q, all_snaps, m_static);
+            }
+            // dynamic rects per snapshot (the leader counts as a static-class object: it sits in game_object_list)
+            for (int a = 0; a < nsnap; a++) {
+                int slot = (snap_count - 1 - a) % hmax;
+                for (int o = 0; o < P.R - 1; o++) {
+                    unsigned sm = (o == 0) ? m_static : m_dyn;
+                    if (!sm) continue;
+                    int4 q = s_snaprect[slot * (P.R - 1) + o];
+                    if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) continue;
+                    test_rect(ry, cx, cy, q, 1u << a, sm);
+                }
+            }
+            // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
+            if (m_corr) for (int p = umin; p + 1 < umax; p++) {
+                unsigned sm = 0;
+#pragma unroll
+                for (int a = 0; a < FTL_HMAX; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
+                if (!sm) continue;
+                float4 u = s_corr[p % c.corr_cap], v = s_corr[(p + 1) % c.corr_cap];
+                if (!(fmaxf(u.x, v.x) < bx0 || fminf(u.x, v.x) > bx1 || fmaxf(u.y, v.y) < by0 || fminf(u.y, v.y) > by1))
+                    test_segment(ry, cx, cy, u.x, u.y, v.x, v.y, sm, m_corr);      // right border
+                if (!(fmaxf(u.z, v.z) < bx0 || fminf(u.z, v.z) > bx1 || fmaxf(u.w, v.w) < by0 || fminf(u.w, v.w) > by1))
+                    test_segment(ry, cx, cy, u.z, u.w, v.z, v.w, sm, m_corr);      // left border
+            }
+            // green-zone end caps of every snapshot (sensors.py:648-650)
+            if (m_green) {
+#pragma unroll
+                for (int a = 0; a < FTL_HMAX; a++) if (a < nsnap) {
+                    float4 u = s_corr[win_lo[a] % c.corr_cap], v = s_corr[(win_hi[a] - 1) % c.corr_cap];
+                    test_segment(ry, cx, cy, u.x, u.y, u.z, u.w, 1u << a, m_green);
+                    test_segment(ry, cx, cy, v.x, v.y, v.z, v.w, 1u << a, m_green);
+                }
+            }
+            // rows: oldest first, newest last (sensors.py:896-901); rows older than the first scan read `miss`
+            if (ry.sensor >= 0) {
+#pragma unroll
+                for (int a = 0; a < FTL_HMAX; a++) {
+                    if (a < H) {
+                        int row = H - 1 - a;
+                        double v = (a < nsnap && ry.best[a] < 1.0e299) ? ry.best[a] : miss;
+                        out_base[ooff + row * N + ray_in_sensor] = (float)v;
+                    }
+                }
+            }
+        }
+    }
 }

@@ -177,7 +177,9 @@ enum {
     FTL_EI_ON_TRACE, FTL_EI_TOO_CLOSE, FTL_EI_STEP_COUNT, FTL_EI_FINISH_TIMER, FTL_EI_TRAJ_LEN,
     FTL_EI_TRK_COUNTER, FTL_EI_CORR_LO, FTL_EI_CORR_HI, FTL_EI_SEED_END, FTL_EI_SNAP_COUNT,
     FTL_EI_DYN_INDEX0, FTL_EI_DYN_INDEX1, FTL_EI_DYN_INDEX2, FTL_EI_DYN_INDEX3,
-    FTL_EI_ERROR, FTL_EI_EPISODES, FTL_EI_GREEN_COUNT, FTL_EI_SPARE, FTL_EI_COUNT
+    FTL_EI_ERROR, FTL_EI_EPISODES, FTL_EI_GREEN_COUNT, FTL_EI_GREEN_LEN,
+    FTL_EI_SCAN_OK,   /* bit g set: the ray sensors of dict-order group g (before / after the tracker's 2nd scan) scanned this step */
+    FTL_EI_SPARE, FTL_EI_COUNT
 };
 /* indices into the "env_dbl" state field; bear waypoints follow at FTL_ED_BEAR_POINTS + 2*b */
 enum { FTL_ED_ACC_PENALTY = 0, FTL_ED_OVERALL_REWARD, FTL_ED_SPARE0, FTL_ED_SPARE1, FTL_ED_BEAR_POINTS,
