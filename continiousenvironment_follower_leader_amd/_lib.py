@@ -40,13 +40,14 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(SO_PATH):
+    so_path = os.environ.get("FTL_LIB", SO_PATH)     # A/B builds of the same sources (tuning only)
+    if not os.path.exists(so_path):
         raise FtlError("libftl_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                        "there is no CPU fallback")
     # PyTorch-ROCm bundles its own HIP runtime; it must be the one already loaded when our library is opened so
     # that both resolve to the SAME libamdhip64 (two runtimes in one process do not see the device).
     import torch  # noqa: F401
-    lib = C.CDLL(SO_PATH)
+    lib = C.CDLL(so_path)
     vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
     lib.ftl_last_error.restype = C.c_char_p
     lib.ftl_create.argtypes = [C.POINTER(abi.Config), i32, i32, C.POINTER(vp)]

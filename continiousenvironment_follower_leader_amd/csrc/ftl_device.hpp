@@ -29,6 +29,12 @@
 #define FTL_WAVE 64
 #define FTL_HMAX 8          // compile-time cap on max_prev_obs (register accumulators)
 #define FTL_DCHUNK 256      // trajectory segment lengths staged per pass of the green-zone walk
+#ifndef FTL_FRAMES_WPE
+#define FTL_FRAMES_WPE 3    // min waves per SIMD the register allocator must leave room for (tuned on MI355X)
+#endif
+#ifndef FTL_RAYS_WPE
+#define FTL_RAYS_WPE 3
+#endif
 
 struct FtlDevParams {
     ftl_config cfg;
@@ -106,6 +112,23 @@ __device__ __forceinline__ double euclid_f32(float ax, float ay, float bx, float
 __device__ __forceinline__ double euclid_f64(double ax, double ay, double bx, double by) {
     double dx = ax - bx, dy = ay - by;
     return sqrt(dx * dx + dy * dy);
+}
+// Threshold tests on those distances.  sqrt is monotone, so away from the threshold the comparison can be made on the
+// squared distance; inside a relative band around thr^2 (wider than every rounding involved) the exact form runs.
+// Both give the same boolean as the reference expression -- only the instruction count differs.
+__device__ __forceinline__ bool euclid_f32_le(float ax, float ay, float bx, float by, double thr) {   // euclid_f32(..) <= thr
+    float dx = ax - bx, dy = ay - by;
+    double x = (double)dx * (double)dx + (double)dy * (double)dy, t2 = thr * thr;
+    if (x < t2 * (1.0 - 1e-6)) return true;
+    if (x > t2 * (1.0 + 1e-6)) return false;
+    return (double)(float)sqrt(x) <= thr;
+}
+__device__ __forceinline__ bool euclid_f64_lt(double ax, double ay, double bx, double by, double thr) { // euclid_f64(..) < thr
+    double dx = ax - bx, dy = ay - by;
+    double x = dx * dx + dy * dy, t2 = thr * thr;
+    if (x < t2 * (1.0 - 1e-12)) return true;
+    if (x > t2 * (1.0 + 1e-12)) return false;
+    return sqrt(x) < thr;
 }
 __device__ __forceinline__ double angle_correction(double a) {   // misc.py:6-13
     if (a >= 360.0) return a - 360.0;
@@ -217,16 +240,24 @@ __device__ __forceinline__ void robot_move(Robot& r, const Limits& L, bool activ
     double direction = r.direction;
     int rx = r.rx, ry = r.ry, rw = r.rw, rh = r.rh;
     bool turning = active && (rot_speed != 0);
-    if (__ballot(turning)) {           // wave-uniform skip of the sincos when no robot of this env rotates
-        if (turning) {
-            direction = angle_correction(direction + rot_dir * rot_speed);
-            int nw, nh, cx = rx + (rw >> 1), cy = ry + (rh >> 1);
-            rotate_size(L.img_w, L.img_h, -direction, nw, nh);
-            rw = nw; rh = nh; rx = cx - (nw >> 1); ry = cy - (nh >> 1);
-        }
-    }
+    if (turning) direction = angle_correction(direction + rot_dir * rot_speed);
     double s, c;
     sincos_bounded(direction * kDeg2Rad, s, c);
+    if (turning) {
+        // New hitbox size = pygame.transform.rotate(image, -direction) (classes.py:173-175).  The bounding box only
+        // needs int(|cos|w+|sin|h): take it from the sin/cos of the movement (the rotate call rounds the angle to
+        // float32, which moves the value by < (w+h)*4e-7) unless that value sits next to an integer or the float32
+        // angle is a multiple of 90 degrees -- then rotate_size() evaluates the reference expression itself.
+        double a32 = (double)(float)(-direction);
+        double vw = fabs(c) * L.img_w + fabs(s) * L.img_h, vh = fabs(s) * L.img_w + fabs(c) * L.img_h;
+        double tol = (double)(L.img_w + L.img_h) * 1e-6;
+        double fw = vw - floor(vw), fh = vh - floor(vh);
+        bool exact = (rint(a32 / 90.0) * 90.0 == a32) || fw < tol || fw > 1.0 - tol || fh < tol || fh > 1.0 - tol;
+        int nw = (int)vw, nh = (int)vh;
+        if (exact) rotate_size(L.img_w, L.img_h, -direction, nw, nh);
+        int cx = rx + (rw >> 1), cy = ry + (rh >> 1);
+        rw = nw; rh = nh; rx = cx - (nw >> 1); ry = cy - (nh >> 1);
+    }
     float mx = (float)(c * speed), my = (float)(s * speed);
     float px = r.px + mx, py = r.py + my;
     double dx = (double)px - (double)(rx + (rw >> 1));
@@ -396,7 +427,8 @@ __device__ __forceinline__ void env_reset(EnvCtx& E, int scen) {
 }
 
 // ---- one frame: ENV:947-1141 ----------------------------------------------------------------------------------
-__device__ __forceinline__ int green_walk(EnvCtx& E) {     // ENV:1828-1843
+// ENV:1828-1843, sequential form: f64 running sum of the segment lengths from the newest point backwards
+__device__ __forceinline__ int green_walk_seq(EnvCtx& E) {
     const float2* tr = reinterpret_cast<const float2*>(traj_ptr(E));
     const double maxd = E.P.cfg.max_distance;
     double acc = 0.0; int G = 0; int k = E.traj_len - 2; bool stop = false;
@@ -408,17 +440,53 @@ __device__ __forceinline__ int green_walk(EnvCtx& E) {     // ENV:1828-1843
             E.s_d[i] = (float)euclid_f32(prev.x, prev.y, cur.x, cur.y);
         }
         __syncthreads();
-        // sequential f64 running sum; acc is monotone, so counting acc<=maxd over the chunk equals the prefix count
-        int i = 0;
-        for (; i + 4 <= cnt; i += 4) {
-            float4 d = *reinterpret_cast<const float4*>(E.s_d + i);
-            acc += (double)d.x; G += (acc <= maxd);
-            acc += (double)d.y; G += (acc <= maxd);
-            acc += (double)d.z; G += (acc <= maxd);
-            acc += (double)d.w; G += (acc <= maxd);
-        }
-        for (; i < cnt; i++) { acc += (double)E.s_d[i]; G += (acc <= maxd); }
+        // acc is monotone, so counting acc<=maxd over the chunk equals the prefix count
+        for (int i = 0; i < cnt; i++) { acc += (double)E.s_d[i]; G += (acc <= maxd); }
         stop = !(acc <= maxd);
+        k -= cnt;
+    }
+    return G;
+}
+// Same count from a wave-parallel prefix sum.  The parallel sums differ from the sequential ones by rounding only
+// (< 1e-10 for any trajectory this state can hold), so whenever no partial sum lies within 1e-6 of max_distance the
+// comparisons -- hence the count -- are identical; otherwise the sequential form decides.
+__device__ __forceinline__ int green_walk(EnvCtx& E) {
+    const float2* tr = reinterpret_cast<const float2*>(traj_ptr(E));
+    const double maxd = E.P.cfg.max_distance;
+    const int lane = E.lane;
+    double base = 0.0; int G = 0; int k = E.traj_len - 2;
+    while (k >= 0) {
+        int cnt = (k + 1 < FTL_DCHUNK) ? k + 1 : FTL_DCHUNK;
+        // lane handles elements 4*lane .. 4*lane+3 of the chunk (element i <-> points k-i, k-i+1)
+        double p[4]; bool valid[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int i = 4 * lane + j;
+            valid[j] = i < cnt;
+            double d = 0.0;
+            if (valid[j]) { float2 cur = tr[k - i], prev = tr[k - i + 1]; d = euclid_f32(prev.x, prev.y, cur.x, cur.y); }
+            p[j] = (j == 0) ? d : p[j - 1] + d;
+        }
+        double incl = p[3];             // inclusive scan of the lane totals
+#pragma unroll
+        for (int off = 1; off < FTL_WAVE; off <<= 1) {
+            double o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        double excl = incl - p[3] + base;
+        bool near = false; int below = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double v = excl + p[j];
+            if (valid[j]) { near |= fabs(v - maxd) < 1e-6; below += (v <= maxd); }
+        }
+        if (__ballot(near) != 0ull) return green_walk_seq(E);
+        // total of `below` over the wave
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) below += __shfl_xor(below, off);
+        G += below;
+        base = rl_d(incl, FTL_WAVE - 1) + base;
+        if (!(base <= maxd)) break;
         k -= cnt;
     }
     return G;
@@ -452,7 +520,7 @@ __device__ __forceinline__ void frame_step(EnvCtx& E, const Limits& L, double& r
     const int orx = E.rb.rx, ory = E.rb.ry, orw = E.rb.rw, orh = E.rb.rh;   // this lane's robot rect before the move
 
     // leader way-point switch (ENV:978-983), uses the leader position before its move
-    if (euclid_f64((double)lpx0, (double)lpy0, E.cur_tx, E.cur_ty) < c.leader_pos_epsilon) {
+    if (euclid_f64_lt((double)lpx0, (double)lpy0, E.cur_tx, E.cur_ty, c.leader_pos_epsilon)) {
         E.cur_target_id += 1;
         if (E.cur_target_id >= E.route_len) E.leader_finished = 1;
         else { const double* rt = route_ptr(E); E.cur_tx = rt[2 * E.cur_target_id]; E.cur_ty = rt[2 * E.cur_target_id + 1]; }
@@ -462,7 +530,7 @@ __device__ __forceinline__ void frame_step(EnvCtx& E, const Limits& L, double& r
     const bool is_bear = lane >= 2 && lane < P.R;
     if (c.n_bears > 0 && is_bear) {
         const int b = lane - 2;
-        bool near = euclid_f64((double)E.rb.px, (double)E.rb.py, E.rb.tgt_x, E.rb.tgt_y) < c.leader_pos_epsilon;
+        bool near = euclid_f64_lt((double)E.rb.px, (double)E.rb.py, E.rb.tgt_x, E.rb.tgt_y, c.leader_pos_epsilon);
         double off, lvl;
         if (c.move_bear_v4 && (b & 1)) {
             if (near) E.rb.dyn_index += 1;
@@ -511,16 +579,15 @@ __device__ __forceinline__ void frame_step(EnvCtx& E, const Limits& L, double& r
         const float2* tr = reinterpret_cast<const float2*>(traj_ptr(E));
         int id = closest_point(E, fpx, fpy, n - 2, -1, G);
         float2 q = tr[n - 2 - id];
-        double d = euclid_f32(fpx, fpy, q.x, q.y);
-        if (d <= c.leader_pos_epsilon) { E.is_on_trace = 1; E.is_in_box = 1; }
-        else if (d <= c.max_dev) { E.is_in_box = 1; E.is_on_trace = 0; }
+        if (euclid_f32_le(fpx, fpy, q.x, q.y, c.leader_pos_epsilon)) { E.is_on_trace = 1; E.is_in_box = 1; }
+        else if (euclid_f32_le(fpx, fpy, q.x, q.y, c.max_dev)) { E.is_in_box = 1; E.is_on_trace = 0; }
         else {
             int id2 = closest_point(E, fpx, fpy, 0, 1, n);
             float2 q2 = tr[id2];
-            if (euclid_f32(fpx, fpy, q2.x, q2.y) <= c.leader_pos_epsilon) { E.is_on_trace = 1; E.is_in_box = 0; }
+            if (euclid_f32_le(fpx, fpy, q2.x, q2.y, c.leader_pos_epsilon)) { E.is_on_trace = 1; E.is_in_box = 0; }
         }
     }
-    E.too_close = euclid_f32(lpx0, lpy0, fpx, fpy) <= c.min_distance;
+    E.too_close = euclid_f32_le(lpx0, lpy0, fpx, fpy, c.min_distance);
 
     // leader collision (ENV:1068-1072): follower + statics, not the bears
     const float lpx = rl_f(E.rb.px, 0), lpy = rl_f(E.rb.py, 0);
@@ -800,7 +867,7 @@ __device__ __forceinline__ void test_rect(Ray& ry, float cx, float cy, int4 q, u
 }  // namespace ftl
 
 // ---------------------------------------------------------------- kernel 1: frames + tracker + observation
-extern "C" __global__ void __launch_bounds__(FTL_WAVE) ftl_frames_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
+extern "C" __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMES_WPE) ftl_frames_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
     using namespace ftl;
     const FtlDevParams& P = *Pp;
@@ -854,7 +921,7 @@ extern "C" __global__ void __launch_bounds__(FTL_WAVE) ftl_frames_kernel(const F
 }
 
 // ---------------------------------------------------------------- kernel 2: the ray casts
-extern "C" __global__ void __launch_bounds__(FTL_WAVE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
+extern "C" __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
     using namespace ftl;
     const FtlDevParams& P = *Pp;
