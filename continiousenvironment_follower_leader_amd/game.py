@@ -1,0 +1,136 @@
+"""``Game`` -- the single-env, gym-style facade over the batched HIP path: same constructor kwargs, ``seed`` /
+``reset`` / ``step`` signatures, observation dict keys / shapes / dtypes, ``info`` strings and spaces as the
+reference's ``class Game(gym.Env)`` (follow_the_leader_continuous_env.py:44-105, 429-543, 908-945, 1789-1824).
+
+reset-time scenario generation (rejection-sampled rocks, D*/A* route; ENV:545-677, 1493-1630) is the next row of the
+scope table and is NOT re-implemented here: ``reset()`` takes its scenario from a pool of
+post-reset scenarios (``scenarios=`` kwarg; e.g. tests/golden/pool_B.npz captured from the reference), and ``seed(v)``
+selects the pool entry ``v mod P``."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import abi
+from .config import make_config
+from .vec_game import ScenarioPool, VecGame
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency of this package)."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        if shape is not None:
+            low, high = np.full(shape, low, dtype=dtype), np.full(shape, high, dtype=dtype)
+        self.low, self.high = np.asarray(low, dtype=dtype), np.asarray(high, dtype=dtype)
+        self.shape, self.dtype = self.low.shape, np.dtype(dtype)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+class Discrete:
+    def __init__(self, n):
+        self.n, self.shape, self.dtype = n, (), np.dtype(np.int64)
+
+    def sample(self):
+        return int(np.random.randint(self.n))
+
+    def contains(self, x):
+        return 0 <= int(x) < self.n
+
+
+def _spaces(cfg):
+    c = cfg.c
+    if cfg.discrete_action_space:                                   # ENV:360-367
+        act = Discrete(5)
+    elif cfg.constant_follower_speed:                               # ENV:368-372
+        act = Box(low=-c.follower.max_rotation_speed, high=c.follower.max_rotation_speed, shape=(1,), dtype=np.float32)
+    else:                                                           # ENV:373-378
+        act = Box(np.array(cfg.action_low, dtype=np.float32), np.array(cfg.action_high, dtype=np.float32))
+    lr, fr = c.leader.max_rotation_speed, c.follower.max_rotation_speed
+    obs = Box(low=np.array((0, 0, 0, 0, -lr, 0, 0, 0, 0, -fr), dtype=np.float32),      # ENV:1812-1824
+              high=np.array((c.width, c.height, c.leader.max_speed, 360, lr,
+                             c.width, c.height, c.follower.max_speed, 360, fr), dtype=np.float32))
+    return act, obs
+
+
+class Game:
+    metadata = {"render.modes": ["rgb_array"]}
+
+    def __init__(self, scenarios=None, device="cuda:0", **kwargs):
+        self.cfg = make_config(**kwargs)
+        self.action_space, self.observation_space = _spaces(self.cfg)
+        self._scenarios = scenarios
+        self._device = device
+        self._vec = None
+        self._seed = 0
+        self.simulation_number = 0
+        self.done = False
+
+    # ------------------------------------------------------------------ gym API
+    def seed(self, seed_value):                                    # ENV:429-432
+        self._seed = int(seed_value)
+
+    def _ensure(self):
+        if self._vec is None:
+            if self._scenarios is None:
+                raise ValueError("Game(scenarios=...) is required: reset-time scenario generation is outside the "
+                                 "accelerated path (see the module docstring)")
+            self._vec = VecGame(1, device=self._device, config=self.cfg)
+            pool = self._scenarios
+            if isinstance(pool, str):
+                pool = ScenarioPool.from_npz(self.cfg, pool, self._device)
+            self._vec.load_scenarios(pool)
+            self._act = torch.zeros(1, 2, dtype=torch.float64, device=self._device)
+
+    def reset(self):                                               # ENV:434-543
+        self._ensure()
+        idx = torch.tensor([self._seed % self._vec.pool.n], dtype=torch.int32)
+        self._vec.reset(idx)
+        self.simulation_number += 1
+        self.done = bool(self._vec.done[0].item())
+        return self._obs()
+
+    def step(self, action):                                        # ENV:908-945
+        cfg = self.cfg
+        if cfg.discrete_action_space:                              # ENV:918-922
+            if type(action) is np.ndarray:
+                assert action.shape[0] == 1 and action.shape[1] == 1
+                action = action[0, 0]
+            action = (cfg.c.follower.max_speed, cfg.discrete_rotation_speed_to_value[action])
+        if cfg.constant_follower_speed:                            # ENV:924-925: np.concatenate([[0.25], action]) -- the
+            action = (0.25, float(np.asarray(action).reshape(-1)[-1]))  # command of ENV:910-911 is overwritten by ENV:927
+        self._act[0, 0] = float(action[0])
+        self._act[0, 1] = float(action[1])
+        self._vec.step(self._act)
+        st = self._vec.status[0].cpu().numpy()
+        info = {"mission_status": abi.MISSION[st[0]], "agent_status": abi.AGENT[st[1]], "leader_status": abi.LEADER[st[2]]}
+        self.done = bool(self._vec.done[0].item())
+        return self._obs(), float(self._vec.reward[0].item()), self.done, info
+
+    def render(self, *a, **k):
+        raise NotImplementedError("rendering (pygame display, ENV:1196-1202) is outside the accelerated path")
+
+    def close(self):
+        if self._vec is not None:
+            self._vec.close()
+            self._vec = None
+
+    # ------------------------------------------------------------------ observation dict (ENV:1789-1810)
+    def _obs(self):
+        v = self._vec
+        obs = OrderedDict()
+        obs["numerical_features"] = v.obs_num[0].cpu().numpy().copy()
+        t = v.target[0].cpu().numpy()
+        obs["leader_target_point"] = (float(t[0]), float(t[1]))
+        for name, cls in self.cfg.sensor_order:
+            if cls == "LeaderPositionsTracker_v2":
+                obs[name] = v.tracker_obs(0)            # (leader_positions_hist, corridor), SEN:324-325
+            else:
+                obs[name] = v.laser_view(name)[0].cpu().numpy().copy()   # [max_prev_obs, lasers_count] float32, SEN:958
+        return obs

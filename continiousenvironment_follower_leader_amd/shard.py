@@ -1,0 +1,59 @@
+"""Multi-GPU sharding of the env batch.
+
+Envs are fully independent: rank r of W owns a contiguous block of env indices, there is no exchange inside
+``step``.  The only collective is an all-reduce of the episode-metrics vector (64 B) every K steps -- RCCL over xGMI
+on GPUs (backend "nccl" is RCCL on ROCm), gloo in the CPU tests."""
+from dataclasses import dataclass
+
+import torch
+
+METRIC_NAMES = ("episodes", "return_sum", "frames_sum", "success", "crash", "low_reward", "too_far", "timeout")
+
+
+@dataclass(frozen=True)
+class Shard:
+    rank: int
+    world: int
+    lo: int
+    hi: int
+
+    @property
+    def n(self):
+        return self.hi - self.lo
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous env range of ``rank``; the first ``n_total % world`` ranks take one extra env."""
+    if not (0 <= rank < world) or n_total < 0:
+        raise ValueError("bad shard request")
+    base, extra = divmod(n_total, world)
+    lo = rank * base + min(rank, extra)
+    return Shard(rank, world, lo, lo + base + (1 if rank < extra else 0))
+
+
+def scenario_index(seed, env_lo, n, pool_size):
+    """Scenario of global env e: pool[(seed*1000003 + e) mod P]; int32 tensor for this shard."""
+    e = torch.arange(env_lo, env_lo + n, dtype=torch.int64)
+    return ((e + seed * 1000003) % pool_size).to(torch.int32)
+
+
+def episode_metrics(done, status, reward_sum, frames):
+    """Per-shard metrics vector [episodes, sum return, sum frames, n_success, n_crash, n_low_reward, n_too_far,
+    n_timeout] (f64[8]) from the outputs of one step; status = [n,3] codes of include/ftl.h."""
+    d = done.bool()
+    st = status
+    f64 = torch.float64
+    zero = torch.zeros((), dtype=f64, device=done.device)
+    return torch.stack([
+        d.sum().to(f64), (reward_sum * d).sum().to(f64) if reward_sum is not None else zero,
+        (frames * d).sum().to(f64) if frames is not None else zero,
+        (d & (st[:, 0] == 2)).sum().to(f64), (d & (st[:, 1] == 1)).sum().to(f64), (d & (st[:, 1] == 2)).sum().to(f64),
+        (d & (st[:, 1] == 3)).sum().to(f64), (d & (st[:, 0] == 3)).sum().to(f64)])
+
+
+def reduce_metrics(vec, group=None):
+    """Sum the metrics vector over all ranks (in place) -- the only collective of the path."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+    return vec

@@ -1,0 +1,89 @@
+"""Host logic: the constructor mirror (config.make_config) against the reference's documented defaults / unit
+conversions (ENV:45-105, 283-357; SURVEY.md 8(c) sanity anchors) and its error behaviour."""
+import math
+
+import pytest
+
+from continiousenvironment_follower_leader_amd import make_config
+from continiousenvironment_follower_leader_amd.game import Game, _spaces
+from golden_util import config_for, load_episode
+
+
+def test_defaults_match_reference_units():
+    c = make_config().c
+    assert (c.width, c.height, c.frames_per_step, c.max_steps, c.warm_start) == (1500, 1000, 10, 5000, 500)
+    assert c.n_static == 37 and c.n_bears == 3 and c.trajectory_saving_period == 5
+    assert (c.min_distance, c.max_distance, c.max_dev, c.leader_pos_epsilon) == (50, 200, 50, 25)
+    f, l, b = c.follower, c.leader, c.bear
+    assert f.max_speed == 0.25 and f.min_speed == 0 and math.isclose(f.max_rotation_speed, 0.57296)
+    assert f.max_speed_change == 0.0025 and f.max_rotation_speed_change == 0.2
+    assert (f.img_w, f.img_h) == (17, 25) and (l.img_w, l.img_h) == (19, 26) and (b.img_w, b.img_h) == (25, 25)
+    assert math.isclose(b.max_speed, 0.275) and b.max_speed_change == 0.25
+    assert (c.reward_in_box, c.reward_in_dev, c.reward_on_track) == (1.0, 0.5, 0.1)
+    assert (c.not_on_track_penalty, c.crash_penalty, c.too_close_penalty, c.leader_movement_reward) == (-1, -10, -5, 0)
+
+
+def test_gazebo_preset_units():
+    # TestGameManual_gazebo numbers (ENV:2015-2040) without the regimes
+    c = make_config(pixels_to_meter=10, min_distance=8, max_distance=15, max_dev=1, follower_size=(1, 1), leader_size=(4, 2),
+                    bear_size=(1.5, 1.5), follower_max_speed=2, leader_max_speed=1, negative_speed=True, bear_number=2,
+                    follower_max_rotation_speed=28.65, leader_max_rotation_speed=28.65, follower_acceleration=1,
+                    leader_acceleration=1, obstacle_number=20, frames_per_step=5, max_steps=30000, warm_start=0,
+                    early_stopping={"max_distance_coef": 4, "low_reward": -300}).c
+    assert c.min_distance == 80 and c.max_distance == 150 and c.follower.min_speed == -0.2 and c.follower.max_speed == 0.2
+    assert c.leader.max_speed == 0.1 and (c.leader.img_w, c.leader.img_h) == (40, 20) and c.n_static == 22
+    assert c.has_low_reward == 1 and c.low_reward == -300 and c.has_max_distance_coef == 1 and c.max_distance_coef == 4
+
+
+def test_sensor_registry_and_dict_order():
+    z, meta = load_episode("B_s1_chase")
+    cfg = config_for(meta)
+    assert cfg.tracker_name == "LeaderPositionsTracker_v2" and cfg.c.tracker_saving_period == 8
+    assert [(l.name, l.count, l.length, l.history, l.after_tracker) for l in cfg.lasers] == [
+        ("LeaderCorridor_lasers_all", 12, 100.0, 5, True), ("LeaderCorridor_lasers_obstacles", 24, 150.0, 5, True)]
+    assert [l.react_obstacles for l in cfg.lasers] == [1, 1] and cfg.lasers[0].react_green and not cfg.lasers[1].react_corridor
+    assert cfg.lasers[0].angle_offset == -45
+    # tracker LAST in the dict (as in server/config/3c1bc/params.json): lasers are scanned before its 2nd scan
+    sens = dict(meta["kwargs"]["follower_sensors"])
+    trk = sens.pop("LeaderPositionsTracker_v2")
+    sens["LeaderPositionsTracker_v2"] = trk
+    cfg2 = make_config(bear_number=1, follower_sensors=sens)
+    assert [l.after_tracker for l in cfg2.lasers] == [False, False]
+
+
+@pytest.mark.parametrize("kw,exc", [
+    (dict(path_finding_algorythm="rrt"), ValueError),                               # ENV:423-425
+    (dict(add_bear=True, bear_number=0), ValueError),                               # ENV:426-427
+    (dict(multiple_end_points=True, path_finding_algorythm="astar"), NotImplementedError),   # ENV:239-243
+    (dict(follower_sensors={"x": {"sensor_class": "LeaderCorridor_Prev_lasers_v2", "lasers_count": 13, "max_prev_obs": 5}}), ValueError),  # SEN:761-762
+    (dict(follower_sensors={"mystery": {}}), ValueError),                            # CLS:249
+    (dict(follower_sensors={"LaserSensor": {}}), NotImplementedError),               # outside the accelerated path
+    (dict(manual_control=True), NotImplementedError),
+    (dict(leader_speed_regime={0: 1}), NotImplementedError),
+    (dict(bear_number=5), NotImplementedError),
+])
+def test_constructor_errors(kw, exc):
+    with pytest.raises(exc):
+        make_config(**kw)
+
+
+def test_unknown_kwargs_are_swallowed_like_the_reference():
+    make_config(some_future_flag=1)        # ENV:104 **kwargs
+
+
+def test_spaces():
+    act, obs = _spaces(make_config())
+    assert act.shape == (2,) and act.low[0] == 0 and math.isclose(float(act.high[1]), 0.57296, rel_tol=1e-6)   # Env_demo.ipynb cell 8
+    assert obs.shape == (10,) and obs.high[0] == 1500 and obs.high[3] == 360
+    act, _ = _spaces(make_config(discrete_action_space=True))
+    assert act.n == 5
+    act, _ = _spaces(make_config(constant_follower_speed=True))
+    assert act.shape == (1,)
+    act, _ = _spaces(make_config(negative_speed=True))
+    assert act.low[0] == -0.25
+
+
+def test_game_facade_needs_scenarios():
+    g = Game(bear_number=1)
+    with pytest.raises(ValueError):
+        g.reset()
