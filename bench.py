@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=4096)
-    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
 
@@ -177,7 +177,8 @@ def main():
                        "episodes_finished": float(metrics[0].item()), "env_error_flags": float(metrics[2].item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ftl_env_kernel", "kernel_ms": kernel_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP},
+                         "kernel": "ftl_frames_kernel + ftl_rays_kernel (one step = both launches, same stream)",
+                         "kernel_ms": kernel_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, pool_path, a.cpu_envs, a.cpu_steps, a.seed)
