@@ -111,7 +111,11 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     h->state_bytes = align_up(cur, 256);
     const size_t lds_static = (size_t)((cfg->n_static + 3) & ~3) * 16 + 16;
     P.lds_frames = (int)(lds_static + FTL_DCHUNK * 16);
-    P.lds_rays = (int)(lds_static + (size_t)hmax * (P.R - 1) * 16 + (size_t)cfg->corr_cap * 16);
+    {   // corridor ring (f32x4) + segment table (f32x4 + u32 mask per entry, worst-case class capacities) + counters
+        const size_t entries = (size_t)(4 * cfg->n_static + 4 * hmax) + (size_t)(4 * hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 4)
+                             + (size_t)2 * cfg->corr_cap + (size_t)2 * hmax;
+        P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + entries * 20 + 64);
+    }
     if (P.lds_frames > 64 * 1024 || P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
     *out = h;
     return FTL_OK;

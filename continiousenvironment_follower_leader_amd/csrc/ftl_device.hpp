@@ -33,7 +33,7 @@
 #define FTL_FRAMES_WPE 3    // min waves per SIMD the register allocator must leave room for (tuned on MI355X)
 #endif
 #ifndef FTL_RAYS_WPE
-#define FTL_RAYS_WPE 3
+#define FTL_RAYS_WPE 4
 #endif
 
 struct FtlDevParams {
@@ -821,47 +821,34 @@ __device__ __forceinline__ void write_obs(EnvCtx& E) {
 }
 
 // ---- LeaderCorridor_Prev_lasers_v2.scan (sensors.py:883-962): the rays ----------------------------------------------
-struct Ray {
-    double ex, ey;        // ray end, float64 (sensors.py:888-891)
-    double best[FTL_HMAX];
-    int sensor;           // -1 = idle lane
-};
+// Segment table entry classes (sensors.py:644-660): which sensors see an entry is decided per class
+enum { SEG_STATIC = 0, SEG_DYNAMIC = 1, SEG_CORRIDOR = 2, SEG_GREEN = 3, SEG_CLASSES = 4 };
 
-// One obstacle segment A->B (float32, as stored by np.array(..., dtype=np.float32), sensors.py:672) against this lane's ray.
-// `snapmask` = history snapshots (by age) that contain the segment, `sensmask` = ray sensors that react to it.
-__device__ __forceinline__ void test_segment(Ray& ry, float cx, float cy, float ax, float ay, float bx, float by,
-                                             unsigned snapmask, unsigned sensmask) {
-    if (ry.sensor < 0 || !((sensmask >> ry.sensor) & 1u)) return;
+// One obstacle segment A->B (float32, as stored by np.array(..., dtype=np.float32), sensors.py:672) against the ray
+// origin C (float32) -> end E (float64).  Returns true on intersection and the SQUARED distance of the intersection
+// point from the origin (sqrt is monotone: min over distances == sqrt of min over squared distances, so the sqrt of
+// sensors.py:920-921 is taken once per output element instead of once per hit).
+__device__ __forceinline__ bool hit_segment(float cx, float cy, double ex, double ey, float4 sg, double& d2) {
+    const float ax = sg.x, ay = sg.y, bx = sg.z, by = sg.w;
     // ccw / intersect with the dtype flow of sensors.py:608-614
     float cax = cx - ax, cay = cy - ay, cbx = cx - bx, cby = cy - by, bax = bx - ax, bay = by - ay;
-    double day = ry.ey - (double)ay, dax = ry.ex - (double)ax, dby = ry.ey - (double)by, dbx = ry.ex - (double)bx;
+    double day = ey - (double)ay, dax = ex - (double)ax, dby = ey - (double)by, dbx = ex - (double)bx;
     bool t1 = day * (double)cax > (double)cay * dax;
     bool t2 = dby * (double)cbx > (double)cby * dbx;
     bool t3 = cay * bax > bay * cax;
     bool t4 = day * (double)bax > (double)bay * dax;
-    if ((t1 != t2) && (t3 != t4)) {
-        // seg_intersect (sensors.py:626-640)
-        double rbx = ry.ex - (double)cx, rby = ry.ey - (double)cy;
-        float dpx = ax - cx, dpy = ay - cy;
-        float dapx = -bay, dapy = bax;
-        double denom = (double)dapx * rbx + (double)dapy * rby;
-        float num = dapx * dpx + dapy * dpy;
-        double t = (double)num / denom;
-        double x = t * rbx + (double)cx, y = t * rby + (double)cy;
-        double qx = x - (double)cx, qy = y - (double)cy;
-        double d = sqrt(qx * qx + qy * qy);
-#pragma unroll
-        for (int j = 0; j < FTL_HMAX; j++)
-            if (((snapmask >> j) & 1u) && d < ry.best[j]) ry.best[j] = d;
-    }
-}
-
-__device__ __forceinline__ void test_rect(Ray& ry, float cx, float cy, int4 q, unsigned snapmask, unsigned sensmask) {
-    float l = (float)q.x, t = (float)q.y, r = (float)(q.x + q.z), b = (float)(q.y + q.w);
-    test_segment(ry, cx, cy, l, b, r, b, snapmask, sensmask);   // bottomleft-bottomright (sensors.py:668-671)
-    test_segment(ry, cx, cy, r, t, r, b, snapmask, sensmask);   // topright-bottomright
-    test_segment(ry, cx, cy, r, t, l, t, snapmask, sensmask);   // topright-topleft
-    test_segment(ry, cx, cy, l, b, l, t, snapmask, sensmask);   // bottomleft-topleft
+    if (!((t1 != t2) && (t3 != t4))) return false;
+    // seg_intersect (sensors.py:626-640)
+    double rbx = ex - (double)cx, rby = ey - (double)cy;
+    float dpx = ax - cx, dpy = ay - cy;
+    float dapx = -bay, dapy = bax;
+    double denom = (double)dapx * rbx + (double)dapy * rby;
+    float num = dapx * dpx + dapy * dpy;
+    double t = (double)num / denom;
+    double x = t * rbx + (double)cx, y = t * rby + (double)cy;
+    double qx = x - (double)cx, qy = y - (double)cy;
+    d2 = qx * qx + qy * qy;
+    return true;
 }
 
 }  // namespace ftl
@@ -921,6 +908,14 @@ extern "C" __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMES_WPE) ftl_frame
 }
 
 // ---------------------------------------------------------------- kernel 2: the ray casts
+// Phase 1 (lane-parallel): every obstacle segment any sensor of this env could see -- static rect edges, the leader /
+//   bear rect edges of the last H snapshots, the corridor polylines and green-zone caps of those snapshots -- is tested
+//   against the sensors' reach around the follower and the survivors are compacted into a per-class segment table in
+//   LDS (segment f32x4 + bit mask of the snapshots that contain it).  A segment wholly outside the reach box cannot
+//   intersect any ray, so dropping it is exact.
+// Phase 2 (per sensor): the 64 lanes are split rays x chunks (12 rays x 5 chunks, 24 x 2, ...): a lane walks every
+//   nch-th table entry of the classes its sensor reacts to, keeping one nearest-hit accumulator per snapshot; chunk
+//   results are min-combined through shuffles and lane (ray, chunk 0) writes the H rows of its ray.
 extern "C" __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
     using namespace ftl;
@@ -931,10 +926,16 @@ extern "C" __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_ke
     if (C.mode == 1 && C.mask && !C.mask[env]) return;
     const int lane = threadIdx.x;
     const int hmax = P.hmax;
-    // LDS: static rects | snapshot rects | f32 corridor ring
-    int4* s_static = reinterpret_cast<int4*>(lds);
-    int4* s_snaprect = reinterpret_cast<int4*>(lds + (size_t)((c.n_static + 3) & ~3) * 16 + 16);
-    float4* s_corr = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(s_snaprect) + (size_t)hmax * (P.R - 1) * 16);
+    const int nrect_dyn = P.R - 1;      // leader + bears per snapshot
+    // LDS: f32 corridor ring | segment table (float4) | masks (u32) | class counters
+    const int cap_static = 4 * c.n_static + 4 * hmax, cap_dyn = 4 * hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 4;
+    const int cap_corr = 2 * c.corr_cap, cap_green = 2 * hmax;
+    const int off1 = cap_static, off2 = off1 + cap_dyn, off3 = off2 + cap_corr, off4 = off3 + cap_green;
+    auto cls_off = [&](int q) { return q == 0 ? 0 : (q == 1 ? off1 : (q == 2 ? off2 : off3)); };
+    float4* s_corr = reinterpret_cast<float4*>(lds);
+    float4* s_seg = s_corr + c.corr_cap;
+    unsigned* s_mask = reinterpret_cast<unsigned*>(s_seg + off4);
+    int* s_cnt = reinterpret_cast<int*>(s_mask + off4);
 
     const int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
     const int scen = ei[FTL_EI_SCEN], snap_count = ei[FTL_EI_SNAP_COUNT], scan_ok = ei[FTL_EI_SCAN_OK];
@@ -942,28 +943,14 @@ extern "C" __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_ke
     const float cx = P.rb_pos[2 * fo], cy = P.rb_pos[2 * fo + 1];
     const double fdir = P.rb_dbl[fo * FTL_RD_COUNT + FTL_RD_DIRECTION];
     float* out_base = C.out.lasers + (size_t)env * P.lasers_len;
-
-    stage_static(s_static, P, scen, lane);
-    {
-        const int4* sr = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)env * hmax * (P.R - 1);
-        for (int i = lane; i < hmax * (P.R - 1); i += FTL_WAVE) s_snaprect[i] = sr[i];
-    }
     const int nsnap = snap_count < hmax ? snap_count : hmax;       // valid snapshots, newest = snap_count-1
+    const unsigned all_snaps = (1u << nsnap) - 1u;                  // bit a = age a (nsnap <= 8)
 
 #pragma nounroll
     for (int which = 0; which < 2; which++) {
-        int total = 0; float lmax = 0.0f;
-        unsigned m_static = 0, m_dyn = 0, m_corr = 0, m_green = 0;
-        for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) {
-            total += c.lasers[k].count; lmax = fmaxf(lmax, (float)c.lasers[k].length);
-            // sensor masks by obstacle class (sensors.py:651-660): statics+leader for True/"all"/"static", bears for True/"all"/"dynamic"
-            int ro = c.lasers[k].react_obstacles;
-            if (ro == 1 || ro == 2) m_static |= 1u << k;
-            if (ro == 1 || ro == 3) m_dyn |= 1u << k;
-            if (c.lasers[k].react_corridor) m_corr |= 1u << k;
-            if (c.lasers[k].react_green) m_green |= 1u << k;
-        }
-        if (total == 0) continue;
+        int n_sens = 0; float lmax = 0.0f;
+        for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) { n_sens++; lmax = fmaxf(lmax, (float)c.lasers[k].length); }
+        if (n_sens == 0) continue;
         if (!((scan_ok >> which) & 1)) {       // sensors.py:893/962: the reference raises UnboundLocalError here
             for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which)
                 for (int i = lane; i < c.lasers[k].history * c.lasers[k].count; i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = (float)c.lasers[k].length;
@@ -985,81 +972,115 @@ extern "C" __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_ke
             }
         }
         __syncthreads();
+        if (lane < SEG_CLASSES) s_cnt[lane] = 0;
         for (int p = umin + lane; p < umax; p += FTL_WAVE) {
             const double* q = corr_slot(P, env, p);
             s_corr[p % c.corr_cap] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
         }
         __syncthreads();
 
-        const float reach = lmax + 2.0f;            // culling radius: a segment entirely outside cannot meet any ray
+        // ---- phase 1: culled, compacted segment table ------------------------------------------------------------------
+        const float reach = lmax + 2.0f;
         const float bx0 = cx - reach, bx1 = cx + reach, by0 = cy - reach, by1 = cy + reach;
-        const unsigned all_snaps = (1u << nsnap) - 1u;   // bit a = age a (nsnap <= 8)
-        for (int base = 0; base < total; base += FTL_WAVE) {      // rays: one per lane, passes of 64
-            Ray ry; ry.sensor = -1; ry.ex = 0; ry.ey = 0;
-            int ray_in_sensor = 0, H = 0, N = 0, ooff = 0;
-            {
-                int q = base + lane, accn = 0;
-                for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) {
-                    if (q >= accn && q < accn + c.lasers[k].count) {
-                        ry.sensor = k; ray_in_sensor = q - accn; H = c.lasers[k].history; N = c.lasers[k].count; ooff = c.lasers[k].out_offset;
-                        double len = c.lasers[k].length, period = 360.0 / (double)N, s, co;
-                        sincos_bounded(((fdir + c.lasers[k].angle_offset) + ray_in_sensor * period) * kDeg2Rad, s, co);
-                        ry.ex = (double)cx + co * len; ry.ey = (double)cy + s * len;
-                    }
-                    accn += c.lasers[k].count;
-                }
-            }
-            // reading when nothing is hit: |end - origin| (sensors.py:925-930)
-            double qx0 = ry.ex - (double)cx, qy0 = ry.ey - (double)cy;
-            const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
-#pragma unroll
-            for (int j = 0; j < FTL_HMAX; j++) ry.best[j] = 1.0e300;
-            // static rects: identical in every snapshot
-            if (m_static) for (int s = 0; s < c.n_static; s++) {
-                int4 q = s_static[s];
-                if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) continue;
-                test_rect(ry, cx, cy, q, all_snaps, m_static);
-            }
-            // dynamic rects per snapshot (the leader counts as a static-class object: it sits in game_object_list)
-            for (int a = 0; a < nsnap; a++) {
+        auto push_rect = [&](int cls, int4 q, unsigned sm) {           // 4 edges in the order of sensors.py:668-671
+            if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) return;
+            int at = cls_off(cls) + atomicAdd(&s_cnt[cls], 4);
+            float l = (float)q.x, t = (float)q.y, r = (float)(q.x + q.z), b = (float)(q.y + q.w);
+            s_seg[at] = make_float4(l, b, r, b); s_seg[at + 1] = make_float4(r, t, r, b);
+            s_seg[at + 2] = make_float4(r, t, l, t); s_seg[at + 3] = make_float4(l, b, l, t);
+            s_mask[at] = sm; s_mask[at + 1] = sm; s_mask[at + 2] = sm; s_mask[at + 3] = sm;
+        };
+        auto push_seg = [&](int cls, float ax, float ay, float bx, float by, unsigned sm, bool cull) {
+            if (cull && (fmaxf(ax, bx) < bx0 || fminf(ax, bx) > bx1 || fmaxf(ay, by) < by0 || fminf(ay, by) > by1)) return;
+            int at = cls_off(cls) + atomicAdd(&s_cnt[cls], 1);
+            s_seg[at] = make_float4(ax, ay, bx, by); s_mask[at] = sm;
+        };
+        {   // static rects straight from the scenario pool: identical in every snapshot
+            const int4* src = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)scen * c.n_static;
+            for (int s = lane; s < c.n_static; s += FTL_WAVE) push_rect(SEG_STATIC, src[s], all_snaps);
+        }
+        {   // leader (a static-class object: it sits in game_object_list) and bears, per snapshot
+            const int4* sr = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)env * hmax * nrect_dyn;
+            for (int i = lane; i < nsnap * nrect_dyn; i += FTL_WAVE) {
+                int a = i / nrect_dyn, o = i - a * nrect_dyn;
                 int slot = (snap_count - 1 - a) % hmax;
-                for (int o = 0; o < P.R - 1; o++) {
-                    unsigned sm = (o == 0) ? m_static : m_dyn;
-                    if (!sm) continue;
-                    int4 q = s_snaprect[slot * (P.R - 1) + o];
-                    if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) continue;
-                    test_rect(ry, cx, cy, q, 1u << a, sm);
+                push_rect(o == 0 ? SEG_STATIC : SEG_DYNAMIC, sr[slot * nrect_dyn + o], 1u << a);
+            }
+        }
+        // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
+        for (int p = umin + lane; p + 1 < umax; p += FTL_WAVE) {
+            unsigned sm = 0;
+#pragma unroll
+            for (int a = 0; a < FTL_HMAX; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
+            if (!sm) continue;
+            float4 u = s_corr[p % c.corr_cap], v = s_corr[(p + 1) % c.corr_cap];
+            push_seg(SEG_CORRIDOR, u.x, u.y, v.x, v.y, sm, true);      // right border
+            push_seg(SEG_CORRIDOR, u.z, u.w, v.z, v.w, sm, true);      // left border
+        }
+        // green-zone end caps of every snapshot (sensors.py:648-650)
+#pragma unroll
+        for (int a = 0; a < FTL_HMAX; a++) if (a < nsnap && lane == a) {
+            float4 u = s_corr[win_lo[a] % c.corr_cap], v = s_corr[(win_hi[a] - 1) % c.corr_cap];
+            push_seg(SEG_GREEN, u.x, u.y, u.z, u.w, 1u << a, true);
+            push_seg(SEG_GREEN, v.x, v.y, v.z, v.w, 1u << a, true);
+        }
+        __syncthreads();
+
+        // ---- phase 2: rays x chunks per sensor -------------------------------------------------------------------------
+#pragma nounroll
+        for (int k = 0; k < c.n_lasers; k++) {
+            if (c.lasers[k].after_tracker != which) continue;
+            const int N = c.lasers[k].count, H = c.lasers[k].history, ooff = c.lasers[k].out_offset;
+            const double len = c.lasers[k].length, aoff = c.lasers[k].angle_offset, period = 360.0 / (double)N;
+            const int ro = c.lasers[k].react_obstacles;
+            unsigned cls_on = 0;          // sensors.py:644-660
+            if (ro == 1 || ro == 2) cls_on |= 1u << SEG_STATIC;
+            if (ro == 1 || ro == 3) cls_on |= 1u << SEG_DYNAMIC;
+            if (c.lasers[k].react_corridor) cls_on |= 1u << SEG_CORRIDOR;
+            if (c.lasers[k].react_green) cls_on |= 1u << SEG_GREEN;
+            for (int base = 0; base < N; base += FTL_WAVE) {
+                const int rp = min(FTL_WAVE, N - base);           // rays in this pass
+                const int nch = FTL_WAVE / rp;                   // chunks per ray
+                const int ray = base + lane % rp, chunk = lane / rp;
+                const bool active = chunk < nch;
+                double s, co;
+                sincos_bounded(((fdir + aoff) + ray * period) * kDeg2Rad, s, co);    // sensors.py:888-891
+                const double ex = (double)cx + co * len, ey = (double)cy + s * len;
+                double best[FTL_HMAX];
+#pragma unroll
+                for (int j = 0; j < FTL_HMAX; j++) best[j] = 1.0e300;
+#pragma nounroll
+                for (int q = 0; q < SEG_CLASSES; q++) {
+                    if (!((cls_on >> q) & 1u)) continue;
+                    const int beg = cls_off(q), end = beg + s_cnt[q];
+                    for (int m0 = beg; m0 < end; m0 += nch) {
+                        const int m = m0 + chunk;
+                        double d2;
+                        if (active && m < end && hit_segment(cx, cy, ex, ey, s_seg[m], d2)) {
+                            const unsigned sm = s_mask[m];
+#pragma unroll
+                            for (int j = 0; j < FTL_HMAX; j++) if (((sm >> j) & 1u) && d2 < best[j]) best[j] = d2;
+                        }
+                    }
                 }
-            }
-            // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
-            if (m_corr) for (int p = umin; p + 1 < umax; p++) {
-                unsigned sm = 0;
+                // combine the chunks of each ray (lanes ray, ray+rp, ray+2rp, ...)
+                for (int ch = 1; ch < nch; ch++) {
 #pragma unroll
-                for (int a = 0; a < FTL_HMAX; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
-                if (!sm) continue;
-                float4 u = s_corr[p % c.corr_cap], v = s_corr[(p + 1) % c.corr_cap];
-                if (!(fmaxf(u.x, v.x) < bx0 || fminf(u.x, v.x) > bx1 || fmaxf(u.y, v.y) < by0 || fminf(u.y, v.y) > by1))
-                    test_segment(ry, cx, cy, u.x, u.y, v.x, v.y, sm, m_corr);      // right border
-                if (!(fmaxf(u.z, v.z) < bx0 || fminf(u.z, v.z) > bx1 || fmaxf(u.w, v.w) < by0 || fminf(u.w, v.w) > by1))
-                    test_segment(ry, cx, cy, u.z, u.w, v.z, v.w, sm, m_corr);      // left border
-            }
-            // green-zone end caps of every snapshot (sensors.py:648-650)
-            if (m_green) {
-#pragma unroll
-                for (int a = 0; a < FTL_HMAX; a++) if (a < nsnap) {
-                    float4 u = s_corr[win_lo[a] % c.corr_cap], v = s_corr[(win_hi[a] - 1) % c.corr_cap];
-                    test_segment(ry, cx, cy, u.x, u.y, u.z, u.w, 1u << a, m_green);
-                    test_segment(ry, cx, cy, v.x, v.y, v.z, v.w, 1u << a, m_green);
+                    for (int j = 0; j < FTL_HMAX; j++) {
+                        double o = __shfl(best[j], (lane % rp) + ch * rp);
+                        if (o < best[j]) best[j] = o;
+                    }
                 }
-            }
-            // rows: oldest first, newest last (sensors.py:896-901); rows older than the first scan read `miss`
-            if (ry.sensor >= 0) {
+                if (chunk == 0) {
+                    // reading when nothing is hit: |end - origin| (sensors.py:925-930); rows: oldest first, newest last
+                    double qx0 = ex - (double)cx, qy0 = ey - (double)cy;
+                    const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
 #pragma unroll
-                for (int a = 0; a < FTL_HMAX; a++) {
-                    if (a < H) {
-                        int row = H - 1 - a;
-                        double v = (a < nsnap && ry.best[a] < 1.0e299) ? ry.best[a] : miss;
-                        out_base[ooff + row * N + ray_in_sensor] = (float)v;
+                    for (int a = 0; a < FTL_HMAX; a++) {
+                        if (a < H) {
+                            double v = (a < nsnap && best[a] < 1.0e299) ? sqrt(best[a]) : miss;
+                            out_base[ooff + (H - 1 - a) * N + ray] = (float)v;
+                        }
                     }
                 }
             }
