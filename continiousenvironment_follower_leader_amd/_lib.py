@@ -12,6 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libftl_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", "ftl_abi.hip"), os.path.join(_PKG, "csrc", "ftl_device.hpp"),
+           os.path.join(_PKG, "csrc", "ftl_frames_group.hpp"),
            os.path.join(_ROOT, "include", "ftl.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the arithmetic must follow the reference operation by operation (no implicit FMA)

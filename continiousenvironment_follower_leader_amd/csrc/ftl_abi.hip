@@ -7,7 +7,10 @@
 #include <new>
 #include <string>
 
+#include <cstdlib>
+
 #include "ftl_device.hpp"
+#include "ftl_frames_group.hpp"
 
 namespace {
 
@@ -187,7 +190,20 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
         h->dirty = false;
     }
-    hipLaunchKernelGGL(ftl_frames_kernel, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_frames, (hipStream_t)stream, h->dP, call);
+    // frame loop: G lanes per env (4 for <= 2 dynamic obstacles, else 8); FTL_FRAMES_V1=1 selects the first-generation
+    // one-wavefront-per-env kernel (kept for A/B measurements)
+    static const bool use_v1 = getenv("FTL_FRAMES_V1") && atoi(getenv("FTL_FRAMES_V1")) != 0;
+    if (use_v1) {
+        hipLaunchKernelGGL(ftl_frames_kernel, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_frames, (hipStream_t)stream, h->dP, call);
+    } else if (h->P.R <= 4) {
+        const int epw = FTL_WAVE / 4;
+        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 16;
+        hipLaunchKernelGGL(ftl_frames_group_kernel<4>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
+    } else {
+        const int epw = FTL_WAVE / 8;
+        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 16;
+        hipLaunchKernelGGL(ftl_frames_group_kernel<8>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
+    }
     if (h->P.cfg.n_lasers > 0)
         hipLaunchKernelGGL(ftl_rays_kernel, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
     e = hipGetLastError();

@@ -1,0 +1,625 @@
+// ftl_frames_group.hpp -- frame-loop kernel, second generation: G lanes per environment, 64/G environments per
+// wavefront (G = 4 for up to 2 dynamic obstacles, G = 8 for up to 4).
+//
+// The first-generation kernel (ftl_frames_kernel) gives one env a whole wavefront and spends most of its
+// instructions on per-env scalar work (controller, sin/cos, atan, reward logic) that only 3 of the 64 lanes need.
+// Here lane (slot, r) holds robot r of env `slot`: the same per-robot instruction stream now advances 16 (or 8) envs,
+// per-env "scalars" are replicated across the G lanes of a group, and the list-shaped work (static-rect collisions,
+// green-zone window, closest trajectory point) is strided over the G lanes of the group with group-local reductions.
+// Cross-lane traffic never leaves a group and is only issued where all lanes of the group are active (loops have
+// group-uniform trip counts, r-dependent branches contain no shuffles), so env-level divergence between groups is safe.
+//
+// Semantics are those of ftl_frames_kernel / oracle/ftl_oracle.c operation by operation; reference citations as there.
+#pragma once
+#include "ftl_device.hpp"
+
+namespace ftl {
+
+// broadcast the value lane K of this lane's group holds
+template <int G, int K>
+__device__ __forceinline__ int gb_i(int v) {
+    if constexpr (G == 4) return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, false);    // quad_perm:[K,K,K,K]
+    else return __shfl(v, (threadIdx.x & ~(G - 1)) + K);
+}
+template <int G, int K> __device__ __forceinline__ float gb_f(float v) { return __int_as_float(gb_i<G, K>(__float_as_int(v))); }
+template <int G, int K> __device__ __forceinline__ double gb_d(double v) {
+    return __hiloint2double(gb_i<G, K>(__double2hiint(v)), gb_i<G, K>(__double2loint(v)));
+}
+template <int G> __device__ __forceinline__ bool group_any(bool p) {
+    unsigned long long m = __ballot(p);
+    return ((m >> (threadIdx.x & ~(G - 1))) & ((1ull << G) - 1ull)) != 0ull;
+}
+template <int G> __device__ __forceinline__ double group_excl_scan(double v, int r, double& total) {   // exclusive prefix sum over the group
+    double incl = v;
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+        double o = __shfl_up(incl, off, G);
+        if (r >= off) incl += o;
+    }
+    total = __shfl(incl, G - 1, G);
+    return incl - v;
+}
+template <int G> __device__ __forceinline__ int group_sum(int v) {
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, G);
+    return v;
+}
+template <int G> __device__ __forceinline__ void group_argmin(float& v, int& idx) {     // first-index ties (np.argmin)
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+        float ov = __shfl_xor(v, off, G);
+        int oi = __shfl_xor(idx, off, G);
+        bool take = (ov < v) || (ov == v && oi < idx);
+        if (take) { v = ov; idx = oi; }
+    }
+}
+
+// per-lane context: robot r of env `env`, env scalars replicated over the group
+struct GCtx {
+    int env, r, slot;
+    bool valid;          // env < n_envs
+    int scen, cur_target_id, leader_finished, done, crash, is_in_box, is_on_trace, too_close;
+    int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
+    int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt;
+    double acc_penalty, overall_reward, cur_tx, cur_ty;
+    Robot rb;
+};
+
+template <int G>
+__device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
+    const int* ei = P.env_int + (size_t)E.env * FTL_EI_COUNT;
+    const double* ed = P.env_dbl + (size_t)E.env * FTL_ED_COUNT;
+    E.scen = ei[FTL_EI_SCEN]; E.cur_target_id = ei[FTL_EI_TARGET_ID]; E.leader_finished = ei[FTL_EI_LEADER_FINISHED];
+    E.done = ei[FTL_EI_DONE]; E.crash = ei[FTL_EI_CRASH]; E.is_in_box = ei[FTL_EI_IN_BOX]; E.is_on_trace = ei[FTL_EI_ON_TRACE];
+    E.too_close = ei[FTL_EI_TOO_CLOSE]; E.step_count = ei[FTL_EI_STEP_COUNT]; E.finish_timer = ei[FTL_EI_FINISH_TIMER];
+    E.traj_len = ei[FTL_EI_TRAJ_LEN]; E.trk_counter = ei[FTL_EI_TRK_COUNTER]; E.corr_lo = ei[FTL_EI_CORR_LO];
+    E.corr_hi = ei[FTL_EI_CORR_HI]; E.seed_end = ei[FTL_EI_SEED_END]; E.snap_count = ei[FTL_EI_SNAP_COUNT];
+    E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
+    E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
+    E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1];
+    int rr = (E.r < P.R) ? E.r : 0;          // idle lanes mirror robot 0 (never committed)
+    size_t ro = (size_t)E.env * P.R + rr;
+    E.rb.px = P.rb_pos[2 * ro]; E.rb.py = P.rb_pos[2 * ro + 1];
+    const double* rd = P.rb_dbl + ro * FTL_RD_COUNT;
+    E.rb.direction = rd[FTL_RD_DIRECTION]; E.rb.speed = rd[FTL_RD_SPEED]; E.rb.rot_speed = rd[FTL_RD_ROT_SPEED];
+    E.rb.des_speed = rd[FTL_RD_DES_SPEED]; E.rb.des_rot_speed = rd[FTL_RD_DES_ROT_SPEED];
+    const int4* ri = reinterpret_cast<const int4*>(P.rb_int + ro * FTL_RI_COUNT);
+    int4 r0 = ri[0], r1 = ri[1];
+    E.rb.rx = r0.x; E.rb.ry = r0.y; E.rb.rw = r0.z; E.rb.rh = r0.w; E.rb.rot_dir = r1.x; E.rb.des_rot_dir = r1.y;
+    int b = (E.r >= 2 && E.r < P.R) ? E.r - 2 : 0;
+    E.rb.tgt_x = ed[FTL_ED_BEAR_POINTS + 2 * b]; E.rb.tgt_y = ed[FTL_ED_BEAR_POINTS + 2 * b + 1];
+    E.rb.dyn_index = ei[FTL_EI_DYN_INDEX0 + b];
+    E.route_len = P.scen.route_len[E.scen];
+}
+
+template <int G>
+__device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
+    if (!E.valid) return;
+    int* ei = P.env_int + (size_t)E.env * FTL_EI_COUNT;
+    double* ed = P.env_dbl + (size_t)E.env * FTL_ED_COUNT;
+    if (E.r == 0) {
+        ei[FTL_EI_SCEN] = E.scen; ei[FTL_EI_TARGET_ID] = E.cur_target_id; ei[FTL_EI_LEADER_FINISHED] = E.leader_finished;
+        ei[FTL_EI_DONE] = E.done; ei[FTL_EI_CRASH] = E.crash; ei[FTL_EI_IN_BOX] = E.is_in_box; ei[FTL_EI_ON_TRACE] = E.is_on_trace;
+        ei[FTL_EI_TOO_CLOSE] = E.too_close; ei[FTL_EI_STEP_COUNT] = E.step_count; ei[FTL_EI_FINISH_TIMER] = E.finish_timer;
+        ei[FTL_EI_TRAJ_LEN] = E.traj_len; ei[FTL_EI_TRK_COUNTER] = E.trk_counter; ei[FTL_EI_CORR_LO] = E.corr_lo;
+        ei[FTL_EI_CORR_HI] = E.corr_hi; ei[FTL_EI_SEED_END] = E.seed_end; ei[FTL_EI_SNAP_COUNT] = E.snap_count;
+        ei[FTL_EI_ERROR] = E.error; ei[FTL_EI_EPISODES] = E.episodes; ei[FTL_EI_GREEN_COUNT] = E.green_count; ei[FTL_EI_GREEN_LEN] = E.green_len;
+        ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SPARE] = 0;
+        ed[FTL_ED_ACC_PENALTY] = E.acc_penalty; ed[FTL_ED_OVERALL_REWARD] = E.overall_reward;
+        ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty;
+    }
+    if (E.r < P.R) {
+        size_t ro = (size_t)E.env * P.R + E.r;
+        P.rb_pos[2 * ro] = E.rb.px; P.rb_pos[2 * ro + 1] = E.rb.py;
+        double* rd = P.rb_dbl + ro * FTL_RD_COUNT;
+        rd[FTL_RD_DIRECTION] = E.rb.direction; rd[FTL_RD_SPEED] = E.rb.speed; rd[FTL_RD_ROT_SPEED] = E.rb.rot_speed;
+        rd[FTL_RD_DES_SPEED] = E.rb.des_speed; rd[FTL_RD_DES_ROT_SPEED] = E.rb.des_rot_speed;
+        int4* ri = reinterpret_cast<int4*>(P.rb_int + ro * FTL_RI_COUNT);
+        ri[0] = make_int4(E.rb.rx, E.rb.ry, E.rb.rw, E.rb.rh); ri[1] = make_int4(E.rb.rot_dir, E.rb.des_rot_dir, 0, 0);
+        if (E.r >= 2) {
+            int b = E.r - 2;
+            ed[FTL_ED_BEAR_POINTS + 2 * b] = E.rb.tgt_x; ed[FTL_ED_BEAR_POINTS + 2 * b + 1] = E.rb.tgt_y;
+            ei[FTL_EI_DYN_INDEX0 + b] = E.rb.dyn_index;
+        }
+    }
+}
+
+// reset(): ENV:494-543 from scenario `scen`; executed by the groups whose `go` is set (group-uniform)
+template <int G>
+__device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen, bool go) {
+    const ftl_config& c = P.cfg;
+    if (go) {
+        E.scen = scen;
+        int rr = (E.r < P.R) ? E.r : 0;
+        size_t so = (size_t)scen * P.R + rr;
+        E.rb.px = P.scen.robot_pos[2 * so]; E.rb.py = P.scen.robot_pos[2 * so + 1];
+        E.rb.direction = P.scen.robot_dir[so];
+        E.rb.speed = 0; E.rb.rot_speed = 0; E.rb.des_speed = 0; E.rb.des_rot_speed = 0; E.rb.rot_dir = 0; E.rb.des_rot_dir = 0;
+        const int4 rr4 = reinterpret_cast<const int4*>(P.scen.robot_rect)[so];
+        E.rb.rx = rr4.x; E.rb.ry = rr4.y; E.rb.rw = rr4.z; E.rb.rh = rr4.w;
+        E.route_len = P.scen.route_len[scen];
+        int n0 = P.scen.init_traj_len[scen];              // initial leader_factual_trajectory (ENV:533-539)
+        const float2* src = reinterpret_cast<const float2*>(P.scen.init_traj) + (size_t)scen * c.init_traj_cap;
+        float2* dst = reinterpret_cast<float2*>(P.traj + (size_t)E.env * c.traj_cap * 2);
+        for (int k = E.r; k < n0; k += G) dst[k] = src[k];
+        E.traj_len = n0;
+        E.step_count = 0; E.acc_penalty = 0; E.overall_reward = 0;
+        E.done = 0; E.crash = 0; E.is_in_box = 0; E.is_on_trace = 0; E.too_close = 0;
+        E.cur_target_id = 1; E.leader_finished = 0; E.finish_timer = -1;
+        E.green_count = 0; E.green_len = -1; E.error = 0; E.scan_ok = 0;
+        E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0;
+    }
+    // group-uniform from here on (go is the same in every lane of a group), so the broadcasts are safe
+    float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py);
+    if (go) {
+        const double* rt = P.scen.route + (size_t)scen * c.route_cap * 2;
+        if (E.route_len == 0) { E.done = 1; E.cur_tx = (double)lpx; E.cur_ty = (double)lpy; }
+        else { int id = E.route_len > 1 ? 1 : 0; E.cur_tx = rt[2 * id]; E.cur_ty = rt[2 * id + 1]; }
+        // ENV:717-718: every bear starts from the LAST bear_start_position, (leader - 150, leader - 150) in float32
+        E.rb.tgt_x = (double)(lpx - 150.0f); E.rb.tgt_y = (double)(lpy - 150.0f); E.rb.dyn_index = 0;
+    }
+}
+
+// static rects that can touch the follower or the leader during this step -> compact per-env list in LDS.
+// A robot's hitbox stays inside pos +- ((w+h)/2 + 1) and pos moves at most frames*max_speed per step, so a rect outside
+// that swept box (plus slack) can never collide during the step: dropping it from the per-frame tests is exact.
+template <int G>
+__device__ __forceinline__ void g_build_near(const FtlDevParams& P, GCtx& E, int4* s_near, int* s_cnt) {
+    const ftl_config& c = P.cfg;
+    const float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py), fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
+    const float F = (float)c.frames_per_step;
+    const float ml = 0.5f * (float)(c.leader.img_w + c.leader.img_h) + 4.0f + F * (float)fmax(fabs(c.leader.max_speed), fabs(c.leader.min_speed));
+    const float mf = 0.5f * (float)(c.follower.img_w + c.follower.img_h) + 4.0f + F * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed));
+    if (E.r == 0) s_cnt[E.slot] = 0;
+    __syncthreads();
+    if (E.valid) {
+        const int4* src = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)E.scen * c.n_static;
+        int4* dst = s_near + (size_t)E.slot * c.n_static;
+        for (int s = E.r; s < c.n_static; s += G) {
+            int4 q = src[s];
+            float x0 = (float)q.x, x1 = (float)(q.x + q.z), y0 = (float)q.y, y1 = (float)(q.y + q.w);
+            bool nl = !(x1 < lpx - ml || x0 > lpx + ml || y1 < lpy - ml || y0 > lpy + ml);
+            bool nf = !(x1 < fpx - mf || x0 > fpx + mf || y1 < fpy - mf || y0 > fpy + mf);
+            if (nl || nf) dst[atomicAdd(&s_cnt[E.slot], 1)] = q;
+        }
+    }
+    __syncthreads();
+    E.near_cnt = s_cnt[E.slot];
+}
+
+// ENV:1828-1843 sequential form for one env, run by every lane of the group redundantly (rare path)
+__device__ __forceinline__ int g_green_seq(const float2* tr, int n, double maxd) {
+    double acc = 0.0; int Gc = 0;
+    for (int k = n - 2; k >= 0; k--) {
+        float2 cur = tr[k], prev = tr[k + 1];
+        acc += euclid_f32(prev.x, prev.y, cur.x, cur.y);
+        if (acc <= maxd) Gc++; else break;
+    }
+    return Gc;
+}
+// group-parallel prefix form with the same exactness argument as green_walk() of the first-generation kernel
+template <int G>
+__device__ __forceinline__ int g_green_walk(const FtlDevParams& P, const GCtx& E) {
+    const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)E.env * P.cfg.traj_cap * 2);
+    const double maxd = P.cfg.max_distance;
+    const int n = E.traj_len, cnt = n - 1;          // elements i = 0..cnt-1 <-> points (n-2-i, n-1-i)
+    double base = 0.0; int Gc = 0; bool near = false;
+    for (int it = 0; it * G < cnt; it++) {          // group-uniform trip count
+        int i = it * G + E.r;
+        bool v = i < cnt;
+        double d = 0.0;
+        if (v) { float2 cur = tr[n - 2 - i], prev = tr[n - 1 - i]; d = euclid_f32(prev.x, prev.y, cur.x, cur.y); }
+        double tot;
+        double pre = group_excl_scan<G>(d, E.r, tot);
+        double val = base + pre + d;
+        near |= v && (fabs(val - maxd) < 1e-6);
+        Gc += (v && val <= maxd) ? 1 : 0;
+        base += tot;
+        if (!(base <= maxd)) break;                 // base is group-uniform
+    }
+    Gc = group_sum<G>(Gc);
+    if (group_any<G>(near)) Gc = g_green_seq(tr, n, maxd);
+    return Gc;
+}
+
+// first-index arg-min of the f32 squared distance to (px,py) over `n` trajectory points, point i = tr[base + i*stride]
+template <int G>
+__device__ __forceinline__ int g_closest(const float2* tr, int r, float px, float py, int base, int stride, int n) {
+    float best = __int_as_float(0x7f800000); int bi = 0x7fffffff;
+    for (int i = r; i < n; i += G) {
+        float2 q = tr[base + i * stride];
+        float dx = q.x - px, dy = q.y - py;
+        float d2 = dx * dx + dy * dy;
+        if (d2 < best) { best = d2; bi = i; }
+    }
+    group_argmin<G>(best, bi);
+    return bi;
+}
+
+template <int G>
+__device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near,
+                                        double& reward, int& i0, int& i1, int& i2) {
+    const ftl_config& c = P.cfg;
+    const int r = E.r;
+    const bool act = E.valid && r < P.R;
+    E.is_in_box = 0; E.is_on_trace = 0;
+    i0 = FTL_MISSION_IN_PROGRESS; i1 = FTL_AGENT_MOVING; i2 = FTL_LEADER_MOVING;
+
+    // the other robots as the follower's collision test and the bears' way-points see them: before anybody moves
+    const float lpx0 = gb_f<G, 0>(E.rb.px), lpy0 = gb_f<G, 0>(E.rb.py);
+    const double ldir0 = gb_d<G, 0>(E.rb.direction);
+    const int orx = E.rb.rx, ory = E.rb.ry, orw = E.rb.rw, orh = E.rb.rh;
+
+    // leader way-point switch (ENV:978-983)
+    if (euclid_f64_lt((double)lpx0, (double)lpy0, E.cur_tx, E.cur_ty, c.leader_pos_epsilon)) {
+        E.cur_target_id += 1;
+        if (E.cur_target_id >= E.route_len) E.leader_finished = 1;
+        else {
+            const double* rt = P.scen.route + ((size_t)E.scen * c.route_cap + E.cur_target_id) * 2;
+            E.cur_tx = rt[0]; E.cur_ty = rt[1];
+        }
+    }
+    // bears: way-point choice (ENV:722-758, 819-837)
+    double tx = E.cur_tx, ty = E.cur_ty;
+    const bool is_bear = act && r >= 2;
+    if (is_bear) {
+        const int b = r - 2;
+        bool near = euclid_f64_lt((double)E.rb.px, (double)E.rb.py, E.rb.tgt_x, E.rb.tgt_y, c.leader_pos_epsilon);
+        double off, lvl;
+        if (c.move_bear_v4 && (b & 1)) {
+            if (near) E.rb.dyn_index += 1;
+            if (E.rb.dyn_index > 3) E.rb.dyn_index = 0;
+            const int order = (b == 1) ? 0x2134 /*p4,p3,p1,p2*/ : 0x4213 /*p3,p1,p2,p4*/;
+            int p = (order >> (4 * E.rb.dyn_index)) & 0xf;
+            lvl = (p <= 2) ? 150.0 : 250.0;
+            off = (p == 1) ? 140.0 : (p == 2) ? -140.0 : (p == 3) ? -160.0 : 160.0;
+        } else {
+            if (near) { E.rb.dyn_index += 1; if (E.rb.dyn_index > 1) E.rb.dyn_index = 0; }
+            lvl = 100.0 * (b + 1);
+            off = (E.rb.dyn_index == 0) ? -130.0 : 130.0;
+        }
+        double s, co;
+        sincos_bounded((ldir0 + off) * kDeg2Rad, s, co);
+        tx = (double)lpx0 + co * lvl; ty = (double)lpy0 + s * lvl;
+        E.rb.tgt_x = tx; E.rb.tgt_y = ty;
+    }
+    bool steers = (act && r == 0 && !E.leader_finished) || is_bear;
+    if (steers) steer_to_point(E.rb, L, tx, ty, r == 0, L.max_speed + 0);
+    if (E.leader_finished) {                                   // ENV:1062-1065
+        if (r == 0) { command_forward(E.rb, L, 0); command_turn(E.rb, L, 0, 0); }
+        i2 = FTL_LEADER_FINISHED;
+    }
+    bool moves = act && !(r == 0 && E.leader_finished);
+    robot_move(E.rb, L, moves);
+
+    const float fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
+    const int frx = gb_i<G, 1>(E.rb.rx), fry = gb_i<G, 1>(E.rb.ry), frw = gb_i<G, 1>(E.rb.rw), frh = gb_i<G, 1>(E.rb.rh);
+    const float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py);
+    const int lrx = gb_i<G, 0>(E.rb.rx), lry = gb_i<G, 0>(E.rb.ry), lrw = gb_i<G, 0>(E.rb.rw), lrh = gb_i<G, 0>(E.rb.rh);
+    // follower + leader collisions against the near statics in one pass (ENV:960-964, 1068-1072, 1176-1194)
+    bool fhit = false, lhit = false;
+    for (int s = r; s < E.near_cnt; s += G) {
+        int4 q = s_near[s];
+        fhit |= rects_collide(frx, fry, frw, frh, q.x, q.y, q.z, q.w);
+        lhit |= rects_collide(lrx, lry, lrw, lrh, q.x, q.y, q.z, q.w);
+    }
+    if (act && r != 1) fhit |= rects_collide(frx, fry, frw, frh, orx, ory, orw, orh);     // leader / bears where they were
+    if (act && r == 1) lhit |= rects_collide(lrx, lry, lrw, lrh, E.rb.rx, E.rb.ry, E.rb.rw, E.rb.rh);   // follower where it is now
+    fhit = group_any<G>(fhit); lhit = group_any<G>(lhit);
+    if (!c.ignore_follower_collisions) {
+        bool out = (double)fpx > (double)c.width || (double)fpy > (double)c.height || fpx < 0.0f || fpy < 0.0f;
+        if (fhit || out) { E.crash = 1; E.done = 1; i0 = FTL_MISSION_FAIL; i1 = FTL_AGENT_CRASH; }
+    }
+    // green zone (ENV:968-969): recomputed when a point was appended
+    const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)E.env * c.traj_cap * 2);
+    if (E.green_len != E.traj_len) { E.green_count = g_green_walk<G>(P, E); E.green_len = E.traj_len; }
+    const int Gc = E.green_count, n = E.traj_len;
+    if (Gc > 2) {                                              // _check_agent_position (ENV:1906-1937)
+        int id = g_closest<G>(tr, r, fpx, fpy, n - 2, -1, Gc);
+        float2 q = tr[n - 2 - id];
+        if (euclid_f32_le(fpx, fpy, q.x, q.y, c.leader_pos_epsilon)) { E.is_on_trace = 1; E.is_in_box = 1; }
+        else if (euclid_f32_le(fpx, fpy, q.x, q.y, c.max_dev)) { E.is_in_box = 1; E.is_on_trace = 0; }
+        else {
+            int id2 = g_closest<G>(tr, r, fpx, fpy, 0, 1, n);
+            float2 q2 = tr[id2];
+            if (euclid_f32_le(fpx, fpy, q2.x, q2.y, c.leader_pos_epsilon)) { E.is_on_trace = 1; E.is_in_box = 0; }
+        }
+    }
+    E.too_close = euclid_f32_le(lpx0, lpy0, fpx, fpy, c.min_distance);
+    {   // leader collision (ENV:1068-1072)
+        bool out = (double)lpx > (double)c.width || (double)lpy > (double)c.height || lpx < 0.0f || lpy < 0.0f;
+        if (lhit || out) { E.done = 1; i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_CRASH; }
+    }
+    // ENV:1074-1075 with the deterministic tick: frame k (1-based since reset) sees get_ticks() == k
+    if ((E.step_count + 1) % c.trajectory_saving_period == 0) {
+        if (E.traj_len < c.traj_cap) {
+            if (E.valid && r == 0) { float2* tw = reinterpret_cast<float2*>(P.traj + (size_t)E.env * c.traj_cap * 2); tw[E.traj_len] = make_float2(lpx, lpy); }
+            E.traj_len += 1;
+        } else E.error |= FTL_ERR_TRAJ_OVERFLOW;
+    }
+    if (E.leader_finished && E.is_in_box) {                 // ENV:1077-1087
+        if (E.finish_timer < 0) E.finish_timer = 0;
+        else {
+            E.finish_timer += 1;
+            if (E.finish_timer > c.frames_per_step * 20) { i0 = FTL_MISSION_SUCCESS; i2 = FTL_LEADER_FINISHED; i1 = FTL_AGENT_FINISHED; E.done = 1; }
+        }
+    }
+    if (E.step_count > c.warm_start) {                      // ENV:1088-1107
+        if (c.has_low_reward && E.acc_penalty < c.low_reward) { i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_LOW_REWARD; E.crash = 1; E.done = 1; }
+        if (c.has_max_distance_coef) {
+            float dx = fpx - lpx, dy = fpy - lpy;
+            float nrm = sqrtf(dx * dx + dy * dy);
+            if (nrm > (float)(c.max_distance * c.max_distance_coef)) { i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_TOO_FAR; E.crash = 1; E.done = 1; }
+        }
+    }
+    double res = 0;                                         // _reward_computation (ENV:1869-1904)
+    res += c.leader_movement_reward;
+    if (E.too_close) res += c.too_close_penalty;
+    else {
+        if (E.is_in_box && E.is_on_trace) res += c.reward_in_box;
+        else if (E.is_in_box) res += c.reward_in_dev;
+        else if (E.is_on_trace) res += c.reward_on_track;
+        else if (E.step_count > c.warm_start) res += c.not_on_track_penalty;
+    }
+    if (E.crash) res += c.crash_penalty;
+    if (res < 0) E.acc_penalty += res; else E.acc_penalty = 0;
+    E.overall_reward += res;
+    E.step_count += 1;
+    if (E.step_count > c.max_steps) { i0 = FTL_MISSION_FINISHED_BY_TIME; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_MOVING; E.done = 1; }
+    reward = c.aggregate_reward ? E.overall_reward : res;
+}
+
+// ---- LeaderPositionsTracker_v2.scan (sensors.py:243-327), one env per group; the sequential parts (numpy pairwise
+// sum, border pairs) are evaluated redundantly by every lane of the group, memory is written by lane r == 0 ------------
+__device__ __forceinline__ double g_hist_dist(const FtlDevParams& P, int env, int i, bool f64) {     // |hist[i] - hist[i+1]| in the array's dtype
+    const double* p = hist_slot(P, env, i); const double* q = hist_slot(P, env, i + 1);
+    if (f64) { double dx = p[0] - q[0], dy = p[1] - q[1]; return sqrt(dx * dx + dy * dy); }
+    float dx = (float)p[0] - (float)q[0], dy = (float)p[1] - (float)q[1];
+    return (double)sqrtf(dx * dx + dy * dy);
+}
+// numpy pairwise sum of the m-1 consecutive distances of hist[lo..hi) without staging them (a[i] = dist(lo+i, lo+i+1));
+// T is the array dtype (float when no seeded float64 point is left).  n <= 128 * 4 (validated on the host).
+template <typename T>
+__device__ __forceinline__ T g_pw128(const FtlDevParams& P, int env, int first, int n, bool f64) {
+    if (n < 8) { T r = (T)0; for (int i = 0; i < n; i++) r += (T)g_hist_dist(P, env, first + i, f64); return r; }
+    T r0 = (T)g_hist_dist(P, env, first, f64), r1 = (T)g_hist_dist(P, env, first + 1, f64), r2 = (T)g_hist_dist(P, env, first + 2, f64),
+      r3 = (T)g_hist_dist(P, env, first + 3, f64), r4 = (T)g_hist_dist(P, env, first + 4, f64), r5 = (T)g_hist_dist(P, env, first + 5, f64),
+      r6 = (T)g_hist_dist(P, env, first + 6, f64), r7 = (T)g_hist_dist(P, env, first + 7, f64);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += (T)g_hist_dist(P, env, first + i, f64); r1 += (T)g_hist_dist(P, env, first + i + 1, f64);
+        r2 += (T)g_hist_dist(P, env, first + i + 2, f64); r3 += (T)g_hist_dist(P, env, first + i + 3, f64);
+        r4 += (T)g_hist_dist(P, env, first + i + 4, f64); r5 += (T)g_hist_dist(P, env, first + i + 5, f64);
+        r6 += (T)g_hist_dist(P, env, first + i + 6, f64); r7 += (T)g_hist_dist(P, env, first + i + 7, f64);
+    }
+    T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += (T)g_hist_dist(P, env, first + i, f64);
+    return res;
+}
+template <typename T, int DEPTH>
+__device__ __forceinline__ T g_pw(const FtlDevParams& P, int env, int first, int n, bool f64) {
+    if (n <= 128) return g_pw128<T>(P, env, first, n, f64);
+    if constexpr (DEPTH == 0) return g_pw128<T>(P, env, first, n, f64);
+    else { int n2 = n / 2; n2 -= n2 % 8; return g_pw<T, DEPTH - 1>(P, env, first, n2, f64) + g_pw<T, DEPTH - 1>(P, env, first + n2, n - n2, f64); }
+}
+__device__ __forceinline__ double g_path_length(const FtlDevParams& P, const GCtx& E, int lo, int hi) {
+    int m = hi - lo;
+    if (m < 2) return 0.0;
+    if (lo < E.seed_end) return g_pw<double, 2>(P, E.env, lo, m - 1, true);
+    return (double)g_pw<float, 2>(P, E.env, lo, m - 1, false);
+}
+__device__ __forceinline__ void g_border_pair(const FtlDevParams& P, const GCtx& E, int i1, int i0, int ia, int at, bool write) {
+    const double* p1 = hist_slot(P, E.env, i1); const double* p0 = hist_slot(P, E.env, i0); const double* a = hist_slot(P, E.env, ia);
+    double vx, vy;
+    if (i1 < E.seed_end || i0 < E.seed_end) {
+        vx = p1[0] - p0[0]; vy = p1[1] - p0[1];
+        double nrm = sqrt(__builtin_fma(vy, vy, vx * vx));
+        double sc = P.cfg.corridor_width / nrm;
+        vx *= sc; vy *= sc;
+    } else {
+        float fx = (float)p1[0] - (float)p0[0], fy = (float)p1[1] - (float)p0[1];
+        float nrm = sqrtf(fx * fx + fy * fy);
+        float sc = (float)P.cfg.corridor_width / nrm;
+        fx *= sc; fy *= sc; vx = (double)fx; vy = (double)fy;
+    }
+    const double c90 = 6.123233995736766e-17, s90 = 1.0, cm90 = 6.123233995736766e-17, sm90 = -1.0;
+    double r0 = (c90 * vx + (-s90) * vy) + a[0], r1 = (s90 * vx + c90 * vy) + a[1];
+    double l0 = (cm90 * vx + (-sm90) * vy) + a[0], l1 = (sm90 * vx + cm90 * vy) + a[1];
+    if (write) { double* q = corr_slot(P, E.env, at); q[0] = r0; q[1] = r1; q[2] = l0; q[3] = l1; }
+}
+
+// Both scans of a step for every env of the wave.  Memory written by one lane is read by the other lanes of its group
+// only after a workgroup barrier; barriers sit at wave-uniform points (the phases below are predicated, not branched).
+template <int G>
+__device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
+    const ftl_config& c = P.cfg;
+    if (!c.has_tracker) { E.scan_ok = 0; return; }
+    int groups = 0;
+    for (int k = 0; k < c.n_lasers; k++) groups |= 1 << (c.lasers[k].after_tracker ? 1 : 0);
+    int ok = 0, w0lo = 0, w0hi = 0;
+    const float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py);
+    const float fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
+    const double fdir = gb_d<G, 1>(E.rb.direction);
+    const bool w = E.valid && E.r == 0;
+#pragma nounroll
+    for (int g = 0; g < 2; g++) {
+        // ---- phase A: decide, append the new history point(s) ---------------------------------------------------------
+        bool save = E.valid && (E.trk_counter % c.tracker_saving_period == 0);
+        bool counted = E.valid;                      // sensors.py:247-251 returns WITHOUT incrementing the counter
+        bool first = false;
+        if (save) {
+            int len = E.corr_hi - E.corr_lo;
+            if (len > 0) {
+                const double* last = hist_slot(P, E.env, E.corr_hi - 1);
+                if (last[0] == (double)lpx && last[1] == (double)lpy) { save = false; counted = false; }
+            }
+            if (save) {
+                first = (len == 0 && E.trk_counter == 0);
+                if (first) {
+                    const double lmax = c.leader.max_speed;
+                    int n;
+                    if (c.tracker_start_behind) {                     // sensors.py:257-272 (float64 seed points)
+                        double s, co;
+                        sincos_bounded(angle_correction(fdir + 180.0) * kDeg2Rad, s, co);
+                        double sx = 50 * co + (double)fpx, sy = 50 * s + (double)fpy;
+                        double dist = euclid_f64(sx, sy, (double)lpx, (double)lpy);
+                        n = (int)(dist / ((double)(c.tracker_saving_period * 5) * lmax));
+                        if (n < 2 || n > c.corr_cap) { E.error |= (n < 2) ? FTL_ERR_TRACKER_SEED : FTL_ERR_CORR_OVERFLOW; save = false; }
+                        else {
+                            double stepx = ((double)lpx - sx) / (n - 1), stepy = ((double)lpy - sy) / (n - 1);
+                            for (int i = E.r; i < n; i += G) {
+                                double x = (stepx == 0) ? ((double)i / (n - 1)) * ((double)lpx - sx) + sx : (double)i * stepx + sx;
+                                double y = (stepy == 0) ? ((double)i / (n - 1)) * ((double)lpy - sy) + sy : (double)i * stepy + sy;
+                                if (i == n - 1) { x = (double)lpx; y = (double)lpy; }
+                                double* h = hist_slot(P, E.env, i); h[0] = x; h[1] = y;
+                            }
+                            E.seed_end = n; E.corr_lo = 0; E.corr_hi = n;
+                        }
+                    } else {                                          // sensors.py:275-284 (np.linspace(f32,f32) is float32)
+                        double dist = euclid_f32(fpx, fpy, lpx, lpy);
+                        n = (int)(dist / ((double)(c.tracker_saving_period * 5) * lmax));
+                        if (n < 2 || n > c.corr_cap) { E.error |= (n < 2) ? FTL_ERR_TRACKER_SEED : FTL_ERR_CORR_OVERFLOW; save = false; }
+                        else {
+                            float stepx = (lpx - fpx) / (float)(n - 1), stepy = (lpy - fpy) / (float)(n - 1);
+                            for (int i = E.r; i < n; i += G) {
+                                float x = (stepx == 0) ? ((float)i / (float)(n - 1)) * (lpx - fpx) + fpx : (float)i * stepx + fpx;
+                                float y = (stepy == 0) ? ((float)i / (float)(n - 1)) * (lpy - fpy) + fpy : (float)i * stepy + fpy;
+                                if (i == n - 1) { x = lpx; y = lpy; }
+                                double* h = hist_slot(P, E.env, i); h[0] = (double)x; h[1] = (double)y;
+                            }
+                            E.seed_end = 0; E.corr_lo = 0; E.corr_hi = n;
+                        }
+                    }
+                } else {                                              // sensors.py:286
+                    int oldest = E.corr_lo;               // the ring must still hold every point a stored snapshot refers to
+                    const int* sw = P.snap_win + (size_t)E.env * P.hmax * 4;
+                    int nsnap = E.snap_count < P.hmax ? E.snap_count : P.hmax;
+                    for (int j = 0; j < nsnap; j++) { int l0 = sw[4 * j], l1 = sw[4 * j + 2]; oldest = min(oldest, min(l0, l1)); }
+                    if (E.corr_hi + 1 - oldest > c.corr_cap) { E.error |= FTL_ERR_CORR_OVERFLOW; save = false; }
+                    else {
+                        if (w) { double* h = hist_slot(P, E.env, E.corr_hi); h[0] = (double)lpx; h[1] = (double)lpy; }
+                        E.corr_hi += 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase B: trim to corridor_length, append the border pair(s) ------------------------------------------------
+        if (save) {
+            double path = g_path_length(P, E, E.corr_lo, E.corr_hi);          // sensors.py:288-297
+            while (path > c.corridor_length) {
+                if (first) E.error |= FTL_ERR_TRACKER_SEED;                   // reference: popleft on the still-empty corridor deque
+                E.corr_lo += 1;
+                path = g_path_length(P, E, E.corr_lo, E.corr_hi);
+            }
+            int m = E.corr_hi - E.corr_lo;
+            if (m > 1) {                                                      // sensors.py:299-317
+                if (first)
+                    for (int i = m - 1 - E.r; i > 0; i -= G)                  // the m-1 initial pairs are independent: strided over the group
+                        g_border_pair(P, E, E.corr_lo + i, E.corr_lo + i - 1, E.corr_lo + m - i - 1, E.corr_lo + m - 1 - i, true);
+                g_border_pair(P, E, E.corr_hi - 1, E.corr_hi - 2, E.corr_hi - 2, E.corr_hi - 1, w);
+            }
+        }
+        if (counted) E.trk_counter += 1;
+        __syncthreads();
+        if ((groups >> g) & 1) {
+            if (E.corr_hi - E.corr_lo > 1) ok |= 1 << g;
+            else E.error |= FTL_ERR_EMPTY_CORRIDOR;
+        }
+        if (g == 0) { w0lo = E.corr_lo; w0hi = E.corr_hi; }
+    }
+    E.scan_ok = ok;
+    if (ok && E.valid) {             // one snapshot per step: dynamic rects + the corridor window each group saw
+        int slot = E.snap_count % P.hmax;
+        int4* sr = reinterpret_cast<int4*>(P.snap_rects) + ((size_t)E.env * P.hmax + slot) * (P.R - 1);
+        if (E.r < P.R && E.r != 1) sr[E.r == 0 ? 0 : E.r - 1] = make_int4(E.rb.rx, E.rb.ry, E.rb.rw, E.rb.rh);
+        if (E.r == 0) {
+            int* sw = P.snap_win + ((size_t)E.env * P.hmax + slot) * 4;
+            bool g0 = ok & 1;
+            sw[0] = g0 ? w0lo : E.corr_lo; sw[1] = g0 ? w0hi : E.corr_hi; sw[2] = E.corr_lo; sw[3] = E.corr_hi;
+        }
+        E.snap_count += 1;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void g_write_obs(const FtlDevParams& P, const FtlCall& C, const GCtx& E) {     // ENV:1789-1810
+    if (!E.valid) return;
+    if (E.r < 2) {
+        float* o = C.out.obs_num + (size_t)E.env * FTL_OBS_NUM + 5 * E.r;
+        o[0] = E.rb.px; o[1] = E.rb.py; o[2] = (float)E.rb.speed; o[3] = (float)E.rb.direction; o[4] = (float)E.rb.rot_speed;
+    }
+    if (E.r == 0) {
+        double tx = E.cur_tx, ty = E.cur_ty;
+        if (E.route_len > 1) {
+            const double* rt = P.scen.route + (size_t)E.scen * P.cfg.route_cap * 2;
+            if (tx == rt[2 * (E.route_len - 1)] && ty == rt[2 * (E.route_len - 1) + 1]) { tx = rt[2 * (E.route_len - 2)]; ty = rt[2 * (E.route_len - 2) + 1]; }
+        }
+        C.out.target[2 * (size_t)E.env] = tx; C.out.target[2 * (size_t)E.env + 1] = ty;
+    }
+}
+
+}  // namespace ftl
+
+#ifndef FTL_FRAMESG_WPE
+#define FTL_FRAMESG_WPE 2
+#endif
+
+template <int G>
+__global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    using namespace ftl;
+    const FtlDevParams& P = *Pp;
+    constexpr int EPW = FTL_WAVE / G;
+    GCtx E;
+    E.slot = threadIdx.x / G; E.r = threadIdx.x % G;
+    E.env = blockIdx.x * EPW + E.slot;
+    E.valid = E.env < P.n_envs;
+    if (!E.valid) E.env = P.n_envs - 1;       // idle groups shadow the last env (loads only; every store is guarded)
+    int4* s_near = reinterpret_cast<int4*>(lds);
+    int* s_cnt = reinterpret_cast<int*>(lds + (size_t)EPW * P.cfg.n_static * 16);
+    E.scan_ok = 0; E.near_cnt = 0;
+    const Limits L = lane_limits(P.cfg, E.r);
+    if (C.mode == 1) {                                   // reset(): ENV:434-543
+        if (C.mask && !C.mask[E.env]) E.valid = false;
+        g_load<G>(P, E);                                 // keeps the state of masked-out envs intact (nothing is stored for them)
+        g_reset<G>(P, E, E.valid ? C.scen_idx[E.env] : E.scen, E.valid);
+        if (E.valid && E.r == 0) {
+            C.out.reward[E.env] = 0.0; C.out.done[E.env] = (uint8_t)E.done;
+            C.out.status[3 * (size_t)E.env] = 0; C.out.status[3 * (size_t)E.env + 1] = 0; C.out.status[3 * (size_t)E.env + 2] = 0;
+        }
+        __syncthreads();
+    } else {                                             // step(action): ENV:908-945
+        g_load<G>(P, E);
+        g_build_near<G>(P, E, s_near, s_cnt);
+        {
+            double a0 = C.action[2 * (size_t)E.env], a1 = C.action[2 * (size_t)E.env + 1];
+            if (E.r == 1) {
+                command_forward(E.rb, L, a0);                                   // ENV:927
+                if (a1 < 0) command_turn(E.rb, L, fabs(a1), -1);                // ENV:928-933
+                else if (a1 > 0) command_turn(E.rb, L, a1, 1);
+                else command_turn(E.rb, L, 0, 0);
+            }
+        }
+        double reward = 0; int i0 = 0, i1 = 0, i2 = 0;
+        const int4* near = s_near + (size_t)E.slot * P.cfg.n_static;
+#pragma nounroll
+        for (int f = 0; f < P.cfg.frames_per_step; f++) {                       // ENV:935-936
+            g_frame<G>(P, E, L, near, reward, i0, i1, i2);
+            __syncthreads();          // an appended trajectory point is read by the other lanes of the group next frame
+        }
+        if (E.valid && E.r == 0) {
+            C.out.reward[E.env] = reward; C.out.done[E.env] = (uint8_t)E.done;
+            C.out.status[3 * (size_t)E.env] = (uint8_t)i0; C.out.status[3 * (size_t)E.env + 1] = (uint8_t)i1; C.out.status[3 * (size_t)E.env + 2] = (uint8_t)i2;
+        }
+        bool go = E.valid && E.done && (C.flags & FTL_STEP_AUTO_RESET);
+        if (__ballot(go) != 0ull) {
+            if (go) E.episodes += 1;
+            g_reset<G>(P, E, go ? (E.scen + P.n_envs) % P.scen.n_scenarios : E.scen, go);
+            __syncthreads();
+        }
+    }
+    g_sensors<G>(P, E);                                  // ENV:937 / ENV:541 (tracker part of use_sensors)
+    g_write_obs<G>(P, C, E);                             // ENV:938
+    g_store<G>(P, E);
+}
