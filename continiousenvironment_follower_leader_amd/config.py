@@ -269,13 +269,16 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
     c.init_traj_cap = int(init_traj_cap) if init_traj_cap else ((init_pts + 7) // 8) * 8
     need = c.init_traj_cap + (c.max_steps + 2 * c.frames_per_step) // 5 + 8
     c.traj_cap = int(traj_cap) if traj_cap else ((need + 63) // 64) * 64
+    def pow2(v):
+        return 1 << max(3, (int(v) - 1).bit_length())
+
     if corr_cap:
-        c.corr_cap = int(corr_cap)
+        c.corr_cap = pow2(corr_cap)       # the tracker rings are indexed with a mask
     elif c.has_tracker:
         # points are >= tracker_saving_period/2 steps of leader motion apart once the leader runs at full speed;
         # seeded points are period*5*v apart.  4x head-room, overflow is detected (FTL_ERR_CORR_OVERFLOW).
         seed_gap = c.tracker_saving_period * 5 * l_max
-        c.corr_cap = max(32, ((int(4 * c.corridor_length / max(seed_gap, 1e-9)) + 15) // 16) * 16)
+        c.corr_cap = pow2(max(32, int(4 * c.corridor_length / max(seed_gap, 1e-9))))
     else:
         c.corr_cap = 16
     c.route_cap = int(route_cap)

@@ -28,7 +28,7 @@ struct ftl_handle {
     bool dirty;
     int device;
     size_t state_bytes;
-    Field fields[10];
+    Field fields[11];
     bool bound, have_scen;
 };
 
@@ -48,7 +48,9 @@ int validate(const ftl_config& c, std::string& why) {
     REQ(c.n_lasers >= 0 && c.n_lasers <= FTL_MAX_LASERS, "n_lasers out of range");
     REQ(c.n_lasers == 0 || c.has_tracker, "ray sensors need the tracker (classes.py:280 would raise NameError)");
     REQ(c.traj_cap >= 8 && c.corr_cap >= 8 && c.corr_cap <= 512 && c.route_cap >= 2 && c.init_traj_cap >= 1, "bad capacities");
+    REQ((c.corr_cap & (c.corr_cap - 1)) == 0, "corr_cap must be a power of two (the tracker rings are indexed with a mask)");
     REQ(c.init_traj_cap <= c.traj_cap, "init_traj_cap > traj_cap");
+    REQ(c.traj_cap % FTL_TRAJ_BLOCK == 0, "traj_cap must be a multiple of FTL_TRAJ_BLOCK");
     if (c.has_tracker) {
         REQ(c.tracker_saving_period > 0, "tracker saving_period must be positive");
         REQ(c.corridor_length > 0 && c.corridor_width > 0, "corridor_length / corridor_width must be positive");
@@ -100,26 +102,25 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
     // state layout: one region per field, [n_envs][per_env], 256-byte aligned
     const size_t n = (size_t)n_envs;
-    struct { const char* name; size_t per_env; int dtype; size_t esz; } spec[10] = {
+    struct { const char* name; size_t per_env; int dtype; size_t esz; } spec[11] = {
         {"rb_pos", (size_t)P.R * 2, 1, 4}, {"rb_dbl", (size_t)P.R * FTL_RD_COUNT, 2, 8}, {"rb_int", (size_t)P.R * FTL_RI_COUNT, 0, 4},
         {"env_int", FTL_EI_COUNT, 0, 4}, {"env_dbl", FTL_ED_COUNT, 2, 8}, {"traj", (size_t)cfg->traj_cap * 2, 1, 4},
         {"hist", (size_t)cfg->corr_cap * 2, 2, 8}, {"corr", (size_t)cfg->corr_cap * 4, 2, 8},
-        {"snap_rects", (size_t)hmax * (P.R - 1) * 4, 0, 4}, {"snap_win", (size_t)hmax * 4, 0, 4}};
+        {"snap_rects", (size_t)hmax * (P.R - 1) * 4, 0, 4}, {"snap_win", (size_t)hmax * 4, 0, 4},
+        {"traj_bb", (size_t)(cfg->traj_cap / FTL_TRAJ_BLOCK) * 4, 1, 4}};
     size_t cur = 0;
-    for (int i = 0; i < 10; i++) {
+    for (int i = 0; i < 11; i++) {
         cur = align_up(cur, 256);
         h->fields[i] = Field{spec[i].name, cur, spec[i].per_env, spec[i].dtype};
         cur += spec[i].per_env * spec[i].esz * n;
     }
     h->state_bytes = align_up(cur, 256);
-    const size_t lds_static = (size_t)((cfg->n_static + 3) & ~3) * 16 + 16;
-    P.lds_frames = (int)(lds_static + FTL_DCHUNK * 16);
     {   // corridor ring (f32x4) + segment table (f32x4 + u32 mask per entry, worst-case class capacities) + counters
         const size_t entries = (size_t)(4 * cfg->n_static + 4 * hmax) + (size_t)(4 * hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 4)
                              + (size_t)2 * cfg->corr_cap + (size_t)2 * hmax;
         P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + entries * 20 + 64);
     }
-    if (P.lds_frames > 64 * 1024 || P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
+    if (P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
     *out = h;
     return FTL_OK;
 }
@@ -142,7 +143,7 @@ size_t ftl_state_bytes(const ftl_handle* h) { return h ? h->state_bytes : 0; }
 
 int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype) {
     if (!h || !name) return fail(FTL_E_INVALID, "null argument");
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < 11; i++)
         if (!strcmp(h->fields[i].name, name)) {
             if (offset) *offset = h->fields[i].offset;
             if (per_env) *per_env = h->fields[i].per_env;
@@ -162,6 +163,7 @@ int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes) {
     P.env_int = (int32_t*)(b + h->fields[3].offset); P.env_dbl = (double*)(b + h->fields[4].offset); P.traj = (float*)(b + h->fields[5].offset);
     P.hist = (double*)(b + h->fields[6].offset); P.corr = (double*)(b + h->fields[7].offset);
     P.snap_rects = (int32_t*)(b + h->fields[8].offset); P.snap_win = (int32_t*)(b + h->fields[9].offset);
+    P.traj_bb = (float*)(b + h->fields[10].offset);
     h->bound = true; h->dirty = true;
     return FTL_OK;
 }
@@ -190,12 +192,8 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
         h->dirty = false;
     }
-    // frame loop: G lanes per env (4 for <= 2 dynamic obstacles, else 8); FTL_FRAMES_V1=1 selects the first-generation
-    // one-wavefront-per-env kernel (kept for A/B measurements)
-    static const bool use_v1 = getenv("FTL_FRAMES_V1") && atoi(getenv("FTL_FRAMES_V1")) != 0;
-    if (use_v1) {
-        hipLaunchKernelGGL(ftl_frames_kernel, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_frames, (hipStream_t)stream, h->dP, call);
-    } else if (h->P.R <= 4) {
+    // frame loop: G lanes per env (4 for <= 2 dynamic obstacles, else 8)
+    if (h->P.R <= 4) {
         const int epw = FTL_WAVE / 4;
         const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 16;
         hipLaunchKernelGGL(ftl_frames_group_kernel<4>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
@@ -204,8 +202,10 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 16;
         hipLaunchKernelGGL(ftl_frames_group_kernel<8>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
     }
-    if (h->P.cfg.n_lasers > 0)
-        hipLaunchKernelGGL(ftl_rays_kernel, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
+    if (h->P.cfg.n_lasers > 0) {
+        if (h->P.hmax <= 5) hipLaunchKernelGGL(ftl_rays_kernel<5>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
+        else hipLaunchKernelGGL(ftl_rays_kernel<8>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
     return FTL_OK;

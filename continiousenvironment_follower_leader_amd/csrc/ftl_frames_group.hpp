@@ -60,7 +60,7 @@ struct GCtx {
     bool valid;          // env < n_envs
     int scen, cur_target_id, leader_finished, done, crash, is_in_box, is_on_trace, too_close;
     int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
-    int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt;
+    int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint;
     double acc_penalty, overall_reward, cur_tx, cur_ty;
     Robot rb;
 };
@@ -75,6 +75,7 @@ __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
     E.traj_len = ei[FTL_EI_TRAJ_LEN]; E.trk_counter = ei[FTL_EI_TRK_COUNTER]; E.corr_lo = ei[FTL_EI_CORR_LO];
     E.corr_hi = ei[FTL_EI_CORR_HI]; E.seed_end = ei[FTL_EI_SEED_END]; E.snap_count = ei[FTL_EI_SNAP_COUNT];
     E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
+    E.snap_head = ei[FTL_EI_SNAP_HEAD]; E.hint = ei[FTL_EI_HINT];
     E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
     E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1];
     int rr = (E.r < P.R) ? E.r : 0;          // idle lanes mirror robot 0 (never committed)
@@ -104,7 +105,7 @@ __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
         ei[FTL_EI_TRAJ_LEN] = E.traj_len; ei[FTL_EI_TRK_COUNTER] = E.trk_counter; ei[FTL_EI_CORR_LO] = E.corr_lo;
         ei[FTL_EI_CORR_HI] = E.corr_hi; ei[FTL_EI_SEED_END] = E.seed_end; ei[FTL_EI_SNAP_COUNT] = E.snap_count;
         ei[FTL_EI_ERROR] = E.error; ei[FTL_EI_EPISODES] = E.episodes; ei[FTL_EI_GREEN_COUNT] = E.green_count; ei[FTL_EI_GREEN_LEN] = E.green_len;
-        ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SPARE] = 0;
+        ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SNAP_HEAD] = E.snap_head; ei[FTL_EI_HINT] = E.hint;
         ed[FTL_ED_ACC_PENALTY] = E.acc_penalty; ed[FTL_ED_OVERALL_REWARD] = E.overall_reward;
         ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty;
     }
@@ -143,11 +144,22 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         float2* dst = reinterpret_cast<float2*>(P.traj + (size_t)E.env * c.traj_cap * 2);
         for (int k = E.r; k < n0; k += G) dst[k] = src[k];
         E.traj_len = n0;
+        // bounding boxes of the blocks of FTL_TRAJ_BLOCK consecutive points (search acceleration, see g_range_argmin)
+        float4* bb = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK);
+        for (int b = E.r; b * FTL_TRAJ_BLOCK < n0; b += G) {
+            float4 box = make_float4(3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f);
+            for (int k = b * FTL_TRAJ_BLOCK; k < n0 && k < (b + 1) * FTL_TRAJ_BLOCK; k++) {
+                float2 q = src[k];
+                box.x = fminf(box.x, q.x); box.y = fminf(box.y, q.y); box.z = fmaxf(box.z, q.x); box.w = fmaxf(box.w, q.y);
+            }
+            bb[b] = box;
+        }
         E.step_count = 0; E.acc_penalty = 0; E.overall_reward = 0;
         E.done = 0; E.crash = 0; E.is_in_box = 0; E.is_on_trace = 0; E.too_close = 0;
         E.cur_target_id = 1; E.leader_finished = 0; E.finish_timer = -1;
         E.green_count = 0; E.green_len = -1; E.error = 0; E.scan_ok = 0;
-        E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0;
+        E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0; E.snap_head = 0;
+        E.hint = 0;
     }
     // group-uniform from here on (go is the same in every lane of a group), so the broadcasts are safe
     float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py);
@@ -226,6 +238,7 @@ __device__ __forceinline__ int g_green_walk(const FtlDevParams& P, const GCtx& E
 template <int G>
 __device__ __forceinline__ int g_closest(const float2* tr, int r, float px, float py, int base, int stride, int n) {
     float best = __int_as_float(0x7f800000); int bi = 0x7fffffff;
+#pragma unroll 8
     for (int i = r; i < n; i += G) {
         float2 q = tr[base + i * stride];
         float dx = q.x - px, dy = q.y - py;
@@ -236,8 +249,52 @@ __device__ __forceinline__ int g_closest(const float2* tr, int r, float px, floa
     return bi;
 }
 
+// arg-min (first index on ties, as np.argmin) of the float32 squared distance to (px,py) over trajectory points
+// [lo, hi), restricted to the blocks whose bounding box comes within sqrt(thr2) of the query.  Every point with
+// d2 <= thr2 lies in such a block, so the result IS the reference's arg-min whenever that arg-min has d2 <= thr2, and
+// "no candidate" (idx == 0x7fffffff) or a result with d2 > thr2 means the reference's arg-min is beyond the threshold
+// too -- which is all the callers need (they compare the arg-min's distance with a threshold <= sqrt(thr2)).
+// `reversed`: the reference enumerates the range from hi-1 down to lo (the green list), ties go to the HIGHER index.
 template <int G>
-__device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near,
+__device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* bb, int r, float px, float py, int lo, int hi,
+                                               float thr2, bool reversed, float& best, int& bi) {
+    best = __int_as_float(0x7f800000); bi = 0x7fffffff;
+    int key = 0x7fffffff;                                     // enumeration order of the reference (smaller = earlier)
+    const int b_lo = lo / FTL_TRAJ_BLOCK, b_hi = (hi - 1) / FTL_TRAJ_BLOCK;
+    for (int b0 = b_lo; b0 <= b_hi; b0 += G) {                // group-uniform trip count
+        int b = b0 + r;
+        bool cand = false;
+        if (b <= b_hi) {
+            float4 box = bb[b];
+            float dx = fmaxf(fmaxf(box.x - px, px - box.z), 0.0f), dy = fmaxf(fmaxf(box.y - py, py - box.w), 0.0f);
+            cand = dx * dx + dy * dy <= thr2;
+        }
+        unsigned m = (unsigned)((__ballot(cand) >> (threadIdx.x & ~(G - 1))) & ((1ull << G) - 1ull));
+        while (m) {                                           // group-uniform: every lane of the group sees the same mask
+            int k = __ffs(m) - 1; m &= m - 1;
+            int s0 = (b0 + k) * FTL_TRAJ_BLOCK;
+            int i0 = max(s0, lo), i1 = min(s0 + FTL_TRAJ_BLOCK, hi);
+#pragma unroll 4
+            for (int i = i0 + r; i < i1; i += G) {
+                float2 q = tr[i];
+                float ddx = q.x - px, ddy = q.y - py;
+                float d2 = ddx * ddx + ddy * ddy;
+                int ky = reversed ? (hi - 1 - i) : i;
+                if (d2 < best || (d2 == best && ky < key)) { best = d2; bi = i; key = ky; }
+            }
+        }
+    }
+    // combine the lanes: smallest d2, then earliest in the reference's enumeration order
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+        float ov = __shfl_xor(best, off, G); int ok = __shfl_xor(key, off, G); int oi = __shfl_xor(bi, off, G);
+        bool take = (ov < best) || (ov == best && ok < key);
+        if (take) { best = ov; key = ok; bi = oi; }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near, int& tick,
                                         double& reward, int& i0, int& i1, int& i2) {
     const ftl_config& c = P.cfg;
     const int r = E.r;
@@ -314,15 +371,55 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)E.env * c.traj_cap * 2);
     if (E.green_len != E.traj_len) { E.green_count = g_green_walk<G>(P, E); E.green_len = E.traj_len; }
     const int Gc = E.green_count, n = E.traj_len;
-    if (Gc > 2) {                                              // _check_agent_position (ENV:1906-1937)
-        int id = g_closest<G>(tr, r, fpx, fpy, n - 2, -1, Gc);
-        float2 q = tr[n - 2 - id];
-        if (euclid_f32_le(fpx, fpy, q.x, q.y, c.leader_pos_epsilon)) { E.is_on_trace = 1; E.is_in_box = 1; }
-        else if (euclid_f32_le(fpx, fpy, q.x, q.y, c.max_dev)) { E.is_in_box = 1; E.is_on_trace = 0; }
-        else {
-            int id2 = g_closest<G>(tr, r, fpx, fpy, 0, 1, n);
-            float2 q2 = tr[id2];
-            if (euclid_f32_le(fpx, fpy, q2.x, q2.y, c.leader_pos_epsilon)) { E.is_on_trace = 1; E.is_in_box = 0; }
+    // _check_agent_position (ENV:1906-1937).  Its two arg-min searches only feed threshold tests: closest green point
+    // within epsilon -> on trace + in box; within max_dev -> in box; otherwise closest point of the WHOLE trajectory
+    // within epsilon -> on trace.  g_range_argmin() returns the reference's arg-min whenever it matters for such a
+    // test; a hint window around the point that was close last frame settles the common on-trace case first.
+    if (Gc > 2) {
+        const double eps = c.leader_pos_epsilon, mdev = c.max_dev;
+        const float4* bb = reinterpret_cast<const float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK);
+        const int g_lo = n - 1 - Gc;                           // green points are indices g_lo .. n-2
+        float wbest = __int_as_float(0x7f800000); int widx = 0x7fffffff;
+        {
+            int w0 = E.hint - 2 * G; w0 = w0 < 0 ? 0 : w0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int i = w0 + k * G + r;
+                if (i < n) {
+                    float2 p = tr[i];
+                    float dx = p.x - fpx, dy = p.y - fpy;
+                    float d2 = dx * dx + dy * dy;
+                    if (d2 < wbest) { wbest = d2; widx = i; }
+                }
+            }
+            group_argmin<G>(wbest, widx);
+        }
+        // "some point is clearly within epsilon" => the arg-min point (smallest float32 squared distance) is too
+        const bool hint_close = wbest < (float)(eps * eps * (1.0 - 1e-5));
+        if (hint_close && widx >= g_lo && widx <= n - 2) {     // a green point is within epsilon
+            E.is_on_trace = 1; E.is_in_box = 1; E.hint = widx;
+        } else {
+            const double far = fmax(mdev, eps);
+            float gb2; int gi;
+            g_range_argmin<G>(tr, bb, r, fpx, fpy, g_lo, n - 1, (float)(far * far * (1.0 + 1e-5)) + 1e-2f, true, gb2, gi);
+            bool in_eps = false, in_dev = false;
+            if (gi != 0x7fffffff) {
+                float2 q = tr[gi];
+                in_eps = euclid_f32_le(fpx, fpy, q.x, q.y, eps);
+                in_dev = !in_eps && euclid_f32_le(fpx, fpy, q.x, q.y, mdev);
+            }
+            if (in_eps) { E.is_on_trace = 1; E.is_in_box = 1; E.hint = gi; }
+            else if (in_dev) { E.is_in_box = 1; E.is_on_trace = 0; E.hint = gi; }
+            else if (hint_close) { E.is_on_trace = 1; E.is_in_box = 0; E.hint = widx; }       // some point is within epsilon
+            else {                                             // closest point of the whole trajectory (ENV:1924-1930)
+                float ab2; int ai;
+                g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, ab2, ai);
+                if (ai != 0x7fffffff) {
+                    float2 q2 = tr[ai];
+                    if (euclid_f32_le(fpx, fpy, q2.x, q2.y, eps)) { E.is_on_trace = 1; E.is_in_box = 0; }
+                    E.hint = ai;
+                }
+            }
         }
     }
     E.too_close = euclid_f32_le(lpx0, lpy0, fpx, fpy, c.min_distance);
@@ -331,9 +428,17 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         if (lhit || out) { E.done = 1; i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_CRASH; }
     }
     // ENV:1074-1075 with the deterministic tick: frame k (1-based since reset) sees get_ticks() == k
-    if ((E.step_count + 1) % c.trajectory_saving_period == 0) {
+    const bool append = tick == 0;           // tick == (step_count + 1) % trajectory_saving_period, kept incrementally
+    tick = (tick + 1 == c.trajectory_saving_period) ? 0 : tick + 1;
+    if (append) {
         if (E.traj_len < c.traj_cap) {
-            if (E.valid && r == 0) { float2* tw = reinterpret_cast<float2*>(P.traj + (size_t)E.env * c.traj_cap * 2); tw[E.traj_len] = make_float2(lpx, lpy); }
+            if (E.valid && r == 0) {
+                float2* tw = reinterpret_cast<float2*>(P.traj + (size_t)E.env * c.traj_cap * 2); tw[E.traj_len] = make_float2(lpx, lpy);
+                float4* bb = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK) + E.traj_len / FTL_TRAJ_BLOCK;
+                float4 box = (E.traj_len % FTL_TRAJ_BLOCK == 0) ? make_float4(lpx, lpy, lpx, lpy) : *bb;
+                box.x = fminf(box.x, lpx); box.y = fminf(box.y, lpy); box.z = fmaxf(box.z, lpx); box.w = fmaxf(box.w, lpy);
+                *bb = box;
+            }
             E.traj_len += 1;
         } else E.error |= FTL_ERR_TRAJ_OVERFLOW;
     }
@@ -530,7 +635,7 @@ __device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
     }
     E.scan_ok = ok;
     if (ok && E.valid) {             // one snapshot per step: dynamic rects + the corridor window each group saw
-        int slot = E.snap_count % P.hmax;
+        int slot = E.snap_head;
         int4* sr = reinterpret_cast<int4*>(P.snap_rects) + ((size_t)E.env * P.hmax + slot) * (P.R - 1);
         if (E.r < P.R && E.r != 1) sr[E.r == 0 ? 0 : E.r - 1] = make_int4(E.rb.rx, E.rb.ry, E.rb.rw, E.rb.rh);
         if (E.r == 0) {
@@ -539,6 +644,7 @@ __device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
             sw[0] = g0 ? w0lo : E.corr_lo; sw[1] = g0 ? w0hi : E.corr_hi; sw[2] = E.corr_lo; sw[3] = E.corr_hi;
         }
         E.snap_count += 1;
+        E.snap_head = (E.snap_head + 1 == P.hmax) ? 0 : E.snap_head + 1;
     }
 }
 
@@ -603,9 +709,10 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         }
         double reward = 0; int i0 = 0, i1 = 0, i2 = 0;
         const int4* near = s_near + (size_t)E.slot * P.cfg.n_static;
+        int tick = (E.step_count + 1) % P.cfg.trajectory_saving_period;
 #pragma nounroll
         for (int f = 0; f < P.cfg.frames_per_step; f++) {                       // ENV:935-936
-            g_frame<G>(P, E, L, near, reward, i0, i1, i2);
+            g_frame<G>(P, E, L, near, tick, reward, i0, i1, i2);
             __syncthreads();          // an appended trajectory point is read by the other lanes of the group next frame
         }
         if (E.valid && E.r == 0) {

@@ -33,6 +33,7 @@ extern "C" {
 #define FTL_MAX_BEARS 4   /* bears with index >= 4 draw from `random` inside step (ENV:750-754): unsupported */
 #define FTL_MAX_LASERS 4
 #define FTL_OBS_NUM 10    /* numerical_features, ENV:1793-1802 */
+#define FTL_TRAJ_BLOCK 32 /* trajectory points per bounding-box block (state field "traj_bb"; traj_cap is a multiple) */
 
 /* error codes */
 #define FTL_OK 0
@@ -155,7 +156,7 @@ size_t ftl_state_bytes(const ftl_handle* h);
 int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes);
 
 /* State introspection for parity tests: byte offset / element count / dtype code of a named field
- * ("rb_pos","rb_dbl","rb_int","env_int","env_dbl","traj","hist","corr","snap_rects","snap_win").
+ * ("rb_pos","rb_dbl","rb_int","env_int","env_dbl","traj","traj_bb","hist","corr","snap_rects","snap_win").
  * dtype: 0 i32, 1 f32, 2 f64.  per_env = elements per env (fields are [n_envs][per_env]). */
 int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype);
 
@@ -179,7 +180,9 @@ enum {
     FTL_EI_DYN_INDEX0, FTL_EI_DYN_INDEX1, FTL_EI_DYN_INDEX2, FTL_EI_DYN_INDEX3,
     FTL_EI_ERROR, FTL_EI_EPISODES, FTL_EI_GREEN_COUNT, FTL_EI_GREEN_LEN,
     FTL_EI_SCAN_OK,   /* bit g set: the ray sensors of dict-order group g (before / after the tracker's 2nd scan) scanned this step */
-    FTL_EI_SPARE, FTL_EI_COUNT
+    FTL_EI_SNAP_HEAD, /* ring slot the next snapshot goes to (= snap_count mod max_prev_obs, kept incrementally) */
+    FTL_EI_HINT,      /* index of a trajectory point that was close to the follower last frame (search hint only) */
+    FTL_EI_COUNT
 };
 /* indices into the "env_dbl" state field; bear waypoints follow at FTL_ED_BEAR_POINTS + 2*b */
 enum { FTL_ED_ACC_PENALTY = 0, FTL_ED_OVERALL_REWARD, FTL_ED_SPARE0, FTL_ED_SPARE1, FTL_ED_BEAR_POINTS,
