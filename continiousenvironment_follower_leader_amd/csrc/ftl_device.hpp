@@ -322,9 +322,12 @@ __device__ __forceinline__ bool hit_segment(float cx, float cy, double ex, doubl
 //   against the sensors' reach around the follower and the survivors are compacted into a per-class segment table in
 //   LDS (segment f32x4 + bit mask of the snapshots that contain it).  A segment wholly outside the reach box cannot
 //   intersect any ray, so dropping it is exact.
-// Phase 2 (per sensor): the 64 lanes are split rays x chunks (12 rays x 5 chunks, 24 x 2, ...): a lane walks every
-//   nch-th table entry of the classes its sensor reacts to, keeping one nearest-hit accumulator per snapshot; chunk
-//   results are min-combined through shuffles and lane (ray, chunk 0) writes the H rows of its ray.
+// Phase 2 (per sensor): ray ends are computed once (one ray per lane) into LDS.  Then one table SEGMENT per lane: the
+//   lane works out which rays can possibly reach its segment -- those whose direction falls inside the arc the segment
+//   subtends at the follower, widened by a slack that dwarfs every rounding error -- and runs the reference's
+//   intersection test only for them (typically 1-4 of the 12/24 rays instead of all).  A hit is folded into the
+//   per-(ray, snapshot) nearest squared distance with a 64-bit LDS atomic min (non-negative doubles order like their
+//   bit patterns); finally one ray per lane turns its H minima into the H output rows.
 // HM = compile-time number of history accumulators (5 covers every in-repo config, 8 is the ABI cap)
 template <int HM>
 __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
@@ -348,6 +351,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     float4* s_seg = s_corr + c.corr_cap;
     unsigned* s_mask = reinterpret_cast<unsigned*>(s_seg + off4);
     int* s_cnt = reinterpret_cast<int*>(s_mask + off4);
+    double2* s_ray = reinterpret_cast<double2*>(reinterpret_cast<unsigned char*>(s_cnt) + 16);       // [max rays of a sensor]
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [rays][HM]
+    const unsigned long long kInfBits = 0x7fefffffffffffffull;                                       // DBL_MAX: "no hit"
 
     const int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
     const int scen = ei[FTL_EI_SCEN], snap_count = ei[FTL_EI_SNAP_COUNT], scan_ok = ei[FTL_EI_SCAN_OK];
@@ -440,7 +446,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         }
         __syncthreads();
 
-        // ---- phase 2: rays x chunks per sensor -------------------------------------------------------------------------
+        // ---- phase 2: segments x candidate rays per sensor ------------------------------------------------------------------
 #pragma nounroll
         for (int k = 0; k < c.n_lasers; k++) {
             if (c.lasers[k].after_tracker != which) continue;
@@ -452,50 +458,74 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             if (ro == 1 || ro == 3) cls_on |= 1u << SEG_DYNAMIC;
             if (c.lasers[k].react_corridor) cls_on |= 1u << SEG_CORRIDOR;
             if (c.lasers[k].react_green) cls_on |= 1u << SEG_GREEN;
-            for (int base = 0; base < N; base += FTL_WAVE) {
-                const int rp = min(FTL_WAVE, N - base);           // rays in this pass
-                const int nch = (int)(64.5f / (float)rp);         // chunks per ray = 64 / rp (exact for these small integers)
-                const int chunk = (int)(((float)lane + 0.5f) / (float)rp), lr = lane - chunk * rp;
-                const int ray = base + lr;
-                const bool active = chunk < nch;
+            __syncthreads();
+            // ray ends (sensors.py:888-891) and accumulators
+            for (int i = lane; i < N; i += FTL_WAVE) {
                 double s, co;
-                sincos_bounded(((fdir + aoff) + ray * period) * kDeg2Rad, s, co);    // sensors.py:888-891
-                const double ex = (double)cx + co * len, ey = (double)cy + s * len;
-                const float ex32 = (float)ex, ey32 = (float)ey;
-                double best[HM];
+                sincos_bounded(((fdir + aoff) + i * period) * kDeg2Rad, s, co);
+                s_ray[i] = make_double2((double)cx + co * len, (double)cy + s * len);
 #pragma unroll
-                for (int j = 0; j < HM; j++) best[j] = 1.0e300;
+                for (int j = 0; j < HM; j++) s_best[i * HM + j] = kInfBits;
+            }
+            __syncthreads();
+            // direction of ray 0 and ray spacing in radians, float32 (candidate selection only)
+            const float phi0 = (float)(((fdir + aoff)) * kDeg2Rad), inv_step = (float)((double)N / 6.283185307179586);
+            const float reachf = (float)len + 2.0f;
 #pragma nounroll
-                for (int q = 0; q < SEG_CLASSES; q++) {
-                    if (!((cls_on >> q) & 1u)) continue;
-                    const int beg = cls_off(q), end = beg + s_cnt[q];
-                    for (int m0 = beg; m0 < end; m0 += nch) {
-                        const int m = m0 + chunk;
+            for (int q = 0; q < SEG_CLASSES; q++) {
+                if (!((cls_on >> q) & 1u)) continue;
+                const int beg = cls_off(q), end = beg + s_cnt[q];
+                for (int m = beg + lane; m < end; m += FTL_WAVE) {
+                    const float4 sg = s_seg[m];
+                    const unsigned sm = s_mask[m];
+                    // candidate rays: the arc [uA, uB] the segment subtends, in units of the ray spacing from ray 0
+                    float ax = sg.x - cx, ay = sg.y - cy, bx = sg.z - cx, by = sg.w - cy;
+                    float uA = (atan2f(ay, ax) - phi0) * inv_step, uB = (atan2f(by, bx) - phi0) * inv_step;
+                    const float fN = (float)N;
+                    uA -= floorf(uA / fN) * fN; uB -= floorf(uB / fN) * fN;          // into [0, N)
+                    float diff = uB - uA; if (diff < 0.0f) diff += fN;
+                    float start = uA, w = diff;
+                    if (diff > 0.5f * fN) { start = uB; w = fN - diff; }
+                    // closest approach of the segment's line to the follower: an arc is only meaningful if it is not tiny
+                    float ex_ = bx - ax, ey_ = by - ay;
+                    float l2 = ex_ * ex_ + ey_ * ey_;
+                    float tt = l2 > 0.0f ? fminf(fmaxf(-(ax * ex_ + ay * ey_) / l2, 0.0f), 1.0f) : 0.0f;
+                    float nx = ax + tt * ex_, ny = ay + tt * ey_;
+                    float dmin2 = nx * nx + ny * ny;
+                    int i0, cnt;
+                    if (dmin2 < 4.0f || w > 0.5f * fN - 0.05f) { i0 = 0; cnt = N; }       // through / next to the origin: every ray
+                    else if (dmin2 > reachf * reachf) { i0 = 0; cnt = 0; }                 // wholly beyond this sensor's reach
+                    else {
+                        const float slack = 0.02f + 0.01f * fN / 6.2831853f;               // >= 0.01 rad, far above float error
+                        i0 = (int)ceilf(start - slack);
+                        cnt = (int)floorf(start + w + slack) - i0 + 1;
+                        cnt = cnt > N ? N : cnt;
+                    }
+                    for (int t = 0; t < cnt; t++) {
+                        int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
+                        const double2 e = s_ray[i];
                         double d2;
-                        if (active && m < end && hit_segment(cx, cy, ex, ey, ex32, ey32, s_seg[m], d2)) {
-                            const unsigned sm = s_mask[m];
+                        if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sg, d2)) {
+                            const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
 #pragma unroll
-                            for (int j = 0; j < HM; j++) best[j] = fmin(best[j], ((sm >> j) & 1u) ? d2 : 1.0e300);
+                            for (int j = 0; j < HM; j++) if ((sm >> j) & 1u) atomicMin(&s_best[i * HM + j], bits);
                         }
                     }
                 }
-                // combine the chunks of each ray (lanes ray, ray+rp, ray+2rp, ...)
-                for (int ch = 1; ch < nch; ch++) {
+            }
+            __syncthreads();
+            // rows: oldest first, newest last (sensors.py:896-901); rows older than the first scan and rays without a
+            // hit read |end - origin| (sensors.py:925-930)
+            for (int i = lane; i < N; i += FTL_WAVE) {
+                const double2 e = s_ray[i];
+                double qx0 = e.x - (double)cx, qy0 = e.y - (double)cy;
+                const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
 #pragma unroll
-                    for (int j = 0; j < HM; j++) {
-                        best[j] = fmin(best[j], __shfl(best[j], lr + ch * rp));
-                    }
-                }
-                if (chunk == 0) {
-                    // reading when nothing is hit: |end - origin| (sensors.py:925-930); rows: oldest first, newest last
-                    double qx0 = ex - (double)cx, qy0 = ey - (double)cy;
-                    const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
-#pragma unroll
-                    for (int a = 0; a < HM; a++) {
-                        if (a < H) {
-                            double v = (a < nsnap && best[a] < 1.0e299) ? sqrt(best[a]) : miss;
-                            out_base[ooff + (H - 1 - a) * N + ray] = (float)v;
-                        }
+                for (int a2 = 0; a2 < HM; a2++) {
+                    if (a2 < H) {
+                        unsigned long long b = s_best[i * HM + a2];
+                        double v = (a2 < nsnap && b != kInfBits) ? sqrt(__longlong_as_double((long long)b)) : miss;
+                        out_base[ooff + (H - 1 - a2) * N + i] = (float)v;
                     }
                 }
             }
