@@ -25,7 +25,9 @@ FTL_STEP_AUTO_RESET = 1
  EI_SNAP_COUNT, EI_DYN_INDEX0, EI_DYN_INDEX1, EI_DYN_INDEX2, EI_DYN_INDEX3, EI_ERROR, EI_EPISODES,
  EI_GREEN_COUNT, EI_GREEN_LEN, EI_SCAN_OK, EI_SNAP_HEAD, EI_HINT, EI_COUNT) = range(28)
 ED_ACC_PENALTY, ED_OVERALL_REWARD, ED_SPARE0, ED_SPARE1, ED_BEAR_POINTS = range(5)
-ED_COUNT = ED_BEAR_POINTS + 2 * FTL_MAX_BEARS
+ED_GREEN_W = ED_BEAR_POINTS + 2 * FTL_MAX_BEARS
+ED_PAD = ED_GREEN_W + 1
+ED_COUNT = ED_PAD + 1
 RD_DIRECTION, RD_SPEED, RD_ROT_SPEED, RD_DES_SPEED, RD_DES_ROT_SPEED, RD_COUNT = range(6)
 RI_X, RI_Y, RI_W, RI_H, RI_ROT_DIR, RI_DES_ROT_DIR, RI_SPARE0, RI_SPARE1, RI_COUNT = range(9)
 

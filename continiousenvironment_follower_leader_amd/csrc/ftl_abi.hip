@@ -198,11 +198,11 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
     // frame loop: G lanes per env (4 for <= 2 dynamic obstacles, else 8)
     if (h->P.R <= 4) {
         const int epw = FTL_WAVE / 4;
-        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 16;
+        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32 + (size_t)epw * (h->P.cfg.traj_cap / FTL_TRAJ_BLOCK) * 16;
         hipLaunchKernelGGL(ftl_frames_group_kernel<4>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
     } else {
         const int epw = FTL_WAVE / 8;
-        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 16;
+        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32 + (size_t)epw * (h->P.cfg.traj_cap / FTL_TRAJ_BLOCK) * 16;
         hipLaunchKernelGGL(ftl_frames_group_kernel<8>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
     }
     if (h->P.cfg.n_lasers > 0) {

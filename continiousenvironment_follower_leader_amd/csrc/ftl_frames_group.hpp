@@ -62,6 +62,7 @@ struct GCtx {
     int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
     int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint;
     double acc_penalty, overall_reward, cur_tx, cur_ty;
+    double green_w;      // running length of the green-zone window (approximate; decisions near the threshold are re-derived exactly)
     Robot rb;
 };
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
     E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
     E.snap_head = ei[FTL_EI_SNAP_HEAD]; E.hint = ei[FTL_EI_HINT];
     E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
-    E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1];
+    E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1]; E.green_w = ed[FTL_ED_GREEN_W];
     int rr = (E.r < P.R) ? E.r : 0;          // idle lanes mirror robot 0 (never committed)
     size_t ro = (size_t)E.env * P.R + rr;
     E.rb.px = P.rb_pos[2 * ro]; E.rb.py = P.rb_pos[2 * ro + 1];
@@ -107,7 +108,7 @@ __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
         ei[FTL_EI_ERROR] = E.error; ei[FTL_EI_EPISODES] = E.episodes; ei[FTL_EI_GREEN_COUNT] = E.green_count; ei[FTL_EI_GREEN_LEN] = E.green_len;
         ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SNAP_HEAD] = E.snap_head; ei[FTL_EI_HINT] = E.hint;
         ed[FTL_ED_ACC_PENALTY] = E.acc_penalty; ed[FTL_ED_OVERALL_REWARD] = E.overall_reward;
-        ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty;
+        ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty; ed[FTL_ED_GREEN_W] = E.green_w; ed[FTL_ED_PAD] = 0.0;
     }
     if (E.r < P.R) {
         size_t ro = (size_t)E.env * P.R + E.r;
@@ -157,7 +158,7 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         E.step_count = 0; E.acc_penalty = 0; E.overall_reward = 0;
         E.done = 0; E.crash = 0; E.is_in_box = 0; E.is_on_trace = 0; E.too_close = 0;
         E.cur_target_id = 1; E.leader_finished = 0; E.finish_timer = -1;
-        E.green_count = 0; E.green_len = -1; E.error = 0; E.scan_ok = 0;
+        E.green_count = 0; E.green_len = -1; E.green_w = 0.0; E.error = 0; E.scan_ok = 0;
         E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0; E.snap_head = 0;
         E.hint = 0;
     }
@@ -211,11 +212,11 @@ __device__ __forceinline__ int g_green_seq(const float2* tr, int n, double maxd)
 }
 // group-parallel prefix form with the same exactness argument as green_walk() of the first-generation kernel
 template <int G>
-__device__ __forceinline__ int g_green_walk(const FtlDevParams& P, const GCtx& E) {
+__device__ __forceinline__ int g_green_walk(const FtlDevParams& P, const GCtx& E, double& wlen) {
     const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)E.env * P.cfg.traj_cap * 2);
     const double maxd = P.cfg.max_distance;
     const int n = E.traj_len, cnt = n - 1;          // elements i = 0..cnt-1 <-> points (n-2-i, n-1-i)
-    double base = 0.0; int Gc = 0; bool near = false;
+    double base = 0.0, wmax = 0.0; int Gc = 0; bool near = false;
     for (int it = 0; it * G < cnt; it++) {          // group-uniform trip count
         int i = it * G + E.r;
         bool v = i < cnt;
@@ -226,11 +227,19 @@ __device__ __forceinline__ int g_green_walk(const FtlDevParams& P, const GCtx& E
         double val = base + pre + d;
         near |= v && (fabs(val - maxd) < 1e-6);
         Gc += (v && val <= maxd) ? 1 : 0;
+        if (v && val <= maxd) wmax = fmax(wmax, val);
         base += tot;
         if (!(base <= maxd)) break;                 // base is group-uniform
     }
     Gc = group_sum<G>(Gc);
-    if (group_any<G>(near)) Gc = g_green_seq(tr, n, maxd);
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, off, G));
+    if (group_any<G>(near)) {
+        Gc = g_green_seq(tr, n, maxd);
+        wmax = 0.0;
+        for (int i = 0; i < Gc; i++) { float2 cur = tr[n - 2 - i], prev = tr[n - 1 - i]; wmax += euclid_f32(prev.x, prev.y, cur.x, cur.y); }
+    }
+    wlen = wmax;
     return Gc;
 }
 
@@ -274,7 +283,7 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
             int k = __ffs(m) - 1; m &= m - 1;
             int s0 = (b0 + k) * FTL_TRAJ_BLOCK;
             int i0 = max(s0, lo), i1 = min(s0 + FTL_TRAJ_BLOCK, hi);
-#pragma unroll 4
+#pragma unroll 8
             for (int i = i0 + r; i < i1; i += G) {
                 float2 q = tr[i];
                 float ddx = q.x - px, ddy = q.y - py;
@@ -294,7 +303,7 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
 }
 
 template <int G>
-__device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near, int& tick,
+__device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near, float4* s_bb, int& tick,
                                         double& reward, int& i0, int& i1, int& i2) {
     const ftl_config& c = P.cfg;
     const int r = E.r;
@@ -369,7 +378,33 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     }
     // green zone (ENV:968-969): recomputed when a point was appended
     const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)E.env * c.traj_cap * 2);
-    if (E.green_len != E.traj_len) { E.green_count = g_green_walk<G>(P, E); E.green_len = E.traj_len; }
+    if (E.green_len != E.traj_len) {
+        // One point was appended since the window was last derived.  The window (ENV:1828-1843: newest segments whose
+        // sequential f64 length sum stays <= max_distance) is slid instead of re-walked: add the new segment, drop the
+        // oldest ones while the running length exceeds max_distance.  The running length differs from the reference's
+        // sums by rounding only (it is re-derived from scratch every 64 points), so every comparison that is not within
+        // 1e-6 of the threshold is the reference's comparison; otherwise the full walk decides.
+        const int nn = E.traj_len;
+        const double maxd = c.max_distance;
+        bool exact = (E.green_len != nn - 1) || (nn % 64 == 0) || E.green_count < 1;
+        int Gn = E.green_count; double W = E.green_w;
+        if (!exact) {
+            float2 p1 = tr[nn - 1], p0 = tr[nn - 2];
+            W += euclid_f32(p1.x, p1.y, p0.x, p0.y); Gn += 1;
+            for (int guard = 0; guard < 64 && Gn > 0 && W > maxd; guard++) {
+                if (fabs(W - maxd) < 1e-6) { exact = true; break; }
+                float2 a = tr[nn - Gn], b = tr[nn - 1 - Gn];       // oldest segment of the window
+                W -= euclid_f32(a.x, a.y, b.x, b.y); Gn -= 1;
+            }
+            if (!exact && (fabs(W - maxd) < 1e-6 || W > maxd || Gn < 1)) exact = true;
+            if (!exact && Gn < nn - 1) {                            // the segment just beyond the window must stay excluded
+                float2 a = tr[nn - 1 - Gn], b = tr[nn - 2 - Gn];
+                if (!(W + euclid_f32(a.x, a.y, b.x, b.y) > maxd + 1e-6)) exact = true;
+            }
+        }
+        if (exact) Gn = g_green_walk<G>(P, E, W);
+        E.green_count = Gn; E.green_w = W; E.green_len = nn;
+    }
     const int Gc = E.green_count, n = E.traj_len;
     // _check_agent_position (ENV:1906-1937).  Its two arg-min searches only feed threshold tests: closest green point
     // within epsilon -> on trace + in box; within max_dev -> in box; otherwise closest point of the WHOLE trajectory
@@ -377,7 +412,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     // test; a hint window around the point that was close last frame settles the common on-trace case first.
     if (Gc > 2) {
         const double eps = c.leader_pos_epsilon, mdev = c.max_dev;
-        const float4* bb = reinterpret_cast<const float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK);
+        const float4* bb = s_bb;                              // block bounding boxes, staged in LDS for the step
         const int g_lo = n - 1 - Gc;                           // green points are indices g_lo .. n-2
         float wbest = __int_as_float(0x7f800000); int widx = 0x7fffffff;
         {
@@ -437,7 +472,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                 float4* bb = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK) + E.traj_len / FTL_TRAJ_BLOCK;
                 float4 box = (E.traj_len % FTL_TRAJ_BLOCK == 0) ? make_float4(lpx, lpy, lpx, lpy) : *bb;
                 box.x = fminf(box.x, lpx); box.y = fminf(box.y, lpy); box.z = fmaxf(box.z, lpx); box.w = fmaxf(box.w, lpy);
-                *bb = box;
+                *bb = box; s_bb[E.traj_len / FTL_TRAJ_BLOCK] = box;
             }
             E.traj_len += 1;
         } else E.error |= FTL_ERR_TRAJ_OVERFLOW;
@@ -684,6 +719,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     if (!E.valid) E.env = P.n_envs - 1;       // idle groups shadow the last env (loads only; every store is guarded)
     int4* s_near = reinterpret_cast<int4*>(lds);
     int* s_cnt = reinterpret_cast<int*>(lds + (size_t)EPW * P.cfg.n_static * 16);
+    float4* s_bb = reinterpret_cast<float4*>(lds + (size_t)EPW * P.cfg.n_static * 16 + (size_t)EPW * 4 + (((size_t)EPW * 4) % 16 ? 16 - ((size_t)EPW * 4) % 16 : 0));
     E.scan_ok = 0; E.near_cnt = 0;
     const Limits L = lane_limits(P.cfg, E.r);
     if (C.mode == 1) {                                   // reset(): ENV:434-543
@@ -709,10 +745,17 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         }
         double reward = 0; int i0 = 0, i1 = 0, i2 = 0;
         const int4* near = s_near + (size_t)E.slot * P.cfg.n_static;
+        const int nblk = P.cfg.traj_cap / FTL_TRAJ_BLOCK;
+        float4* bbl = s_bb + (size_t)E.slot * nblk;               // this env's block bounding boxes for the step
+        {
+            const float4* bbg = reinterpret_cast<const float4*>(P.traj_bb) + (size_t)E.env * nblk;
+            for (int b = E.r; b * FTL_TRAJ_BLOCK < E.traj_len; b += G) bbl[b] = bbg[b];
+        }
+        __syncthreads();
         int tick = (E.step_count + 1) % P.cfg.trajectory_saving_period;
 #pragma nounroll
         for (int f = 0; f < P.cfg.frames_per_step; f++) {                       // ENV:935-936
-            g_frame<G>(P, E, L, near, tick, reward, i0, i1, i2);
+            g_frame<G>(P, E, L, near, bbl, tick, reward, i0, i1, i2);
             __syncthreads();          // an appended trajectory point is read by the other lanes of the group next frame
         }
         if (E.valid && E.r == 0) {

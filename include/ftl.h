@@ -186,7 +186,8 @@ enum {
 };
 /* indices into the "env_dbl" state field; bear waypoints follow at FTL_ED_BEAR_POINTS + 2*b */
 enum { FTL_ED_ACC_PENALTY = 0, FTL_ED_OVERALL_REWARD, FTL_ED_SPARE0, FTL_ED_SPARE1, FTL_ED_BEAR_POINTS,
-       FTL_ED_COUNT = FTL_ED_BEAR_POINTS + 2 * FTL_MAX_BEARS };
+       FTL_ED_GREEN_W = FTL_ED_BEAR_POINTS + 2 * FTL_MAX_BEARS, /* running length of the green-zone window (search acceleration) */
+       FTL_ED_PAD, FTL_ED_COUNT };
 /* per robot: rb_dbl[5] and rb_int[8] */
 enum { FTL_RD_DIRECTION = 0, FTL_RD_SPEED, FTL_RD_ROT_SPEED, FTL_RD_DES_SPEED, FTL_RD_DES_ROT_SPEED, FTL_RD_COUNT };
 enum { FTL_RI_X = 0, FTL_RI_Y, FTL_RI_W, FTL_RI_H, FTL_RI_ROT_DIR, FTL_RI_DES_ROT_DIR, FTL_RI_SPARE0, FTL_RI_SPARE1, FTL_RI_COUNT };
