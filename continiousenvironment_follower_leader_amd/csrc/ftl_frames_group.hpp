@@ -60,7 +60,7 @@ struct GCtx {
     bool valid;          // env < n_envs
     int scen, cur_target_id, leader_finished, done, crash, is_in_box, is_on_trace, too_close;
     int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
-    int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint;
+    int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint, green_tiny;
     double acc_penalty, overall_reward, cur_tx, cur_ty;
     double green_w;      // running length of the green-zone window (approximate; decisions near the threshold are re-derived exactly)
     Robot rb;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
     E.traj_len = ei[FTL_EI_TRAJ_LEN]; E.trk_counter = ei[FTL_EI_TRK_COUNTER]; E.corr_lo = ei[FTL_EI_CORR_LO];
     E.corr_hi = ei[FTL_EI_CORR_HI]; E.seed_end = ei[FTL_EI_SEED_END]; E.snap_count = ei[FTL_EI_SNAP_COUNT];
     E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
-    E.snap_head = ei[FTL_EI_SNAP_HEAD]; E.hint = ei[FTL_EI_HINT];
+    E.snap_head = ei[FTL_EI_SNAP_HEAD]; E.hint = ei[FTL_EI_HINT]; E.green_tiny = ei[FTL_EI_GREEN_TINY];
     E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
     E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1]; E.green_w = ed[FTL_ED_GREEN_W];
     int rr = (E.r < P.R) ? E.r : 0;          // idle lanes mirror robot 0 (never committed)
@@ -106,7 +106,7 @@ __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
         ei[FTL_EI_TRAJ_LEN] = E.traj_len; ei[FTL_EI_TRK_COUNTER] = E.trk_counter; ei[FTL_EI_CORR_LO] = E.corr_lo;
         ei[FTL_EI_CORR_HI] = E.corr_hi; ei[FTL_EI_SEED_END] = E.seed_end; ei[FTL_EI_SNAP_COUNT] = E.snap_count;
         ei[FTL_EI_ERROR] = E.error; ei[FTL_EI_EPISODES] = E.episodes; ei[FTL_EI_GREEN_COUNT] = E.green_count; ei[FTL_EI_GREEN_LEN] = E.green_len;
-        ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SNAP_HEAD] = E.snap_head; ei[FTL_EI_HINT] = E.hint;
+        ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SNAP_HEAD] = E.snap_head; ei[FTL_EI_HINT] = E.hint; ei[FTL_EI_GREEN_TINY] = E.green_tiny; ei[FTL_EI_PAD] = 0;
         ed[FTL_ED_ACC_PENALTY] = E.acc_penalty; ed[FTL_ED_OVERALL_REWARD] = E.overall_reward;
         ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty; ed[FTL_ED_GREEN_W] = E.green_w; ed[FTL_ED_PAD] = 0.0;
     }
@@ -158,7 +158,7 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         E.step_count = 0; E.acc_penalty = 0; E.overall_reward = 0;
         E.done = 0; E.crash = 0; E.is_in_box = 0; E.is_on_trace = 0; E.too_close = 0;
         E.cur_target_id = 1; E.leader_finished = 0; E.finish_timer = -1;
-        E.green_count = 0; E.green_len = -1; E.green_w = 0.0; E.error = 0; E.scan_ok = 0;
+        E.green_count = 0; E.green_len = -1; E.green_w = 0.0; E.green_tiny = 0; E.error = 0; E.scan_ok = 0;
         E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0; E.snap_head = 0;
         E.hint = 0;
     }
@@ -211,30 +211,47 @@ __device__ __forceinline__ int g_green_seq(const float2* tr, int n, double maxd)
     return Gc;
 }
 // group-parallel prefix form with the same exactness argument as green_walk() of the first-generation kernel
+// Segment lengths are float32 values.  While every non-zero one is >= kTinySeg, all of them are multiples of 2^-43 and
+// every partial sum stays below 2^9, so float64 addition of them is EXACT: any summation order reproduces the
+// reference's sequential sums bit for bit.  Only a window that holds a shorter segment needs the tolerance band.
+static constexpr double kTinySeg = 9.5367431640625e-07;   // 2^-20
 template <int G>
-__device__ __forceinline__ int g_green_walk(const FtlDevParams& P, const GCtx& E, double& wlen) {
+__device__ __forceinline__ int g_green_walk(const FtlDevParams& P, const GCtx& E, double& wlen, int& tiny) {
     const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)E.env * P.cfg.traj_cap * 2);
     const double maxd = P.cfg.max_distance;
     const int n = E.traj_len, cnt = n - 1;          // elements i = 0..cnt-1 <-> points (n-2-i, n-1-i)
-    double base = 0.0, wmax = 0.0; int Gc = 0; bool near = false;
-    for (int it = 0; it * G < cnt; it++) {          // group-uniform trip count
-        int i = it * G + E.r;
-        bool v = i < cnt;
-        double d = 0.0;
-        if (v) { float2 cur = tr[n - 2 - i], prev = tr[n - 1 - i]; d = euclid_f32(prev.x, prev.y, cur.x, cur.y); }
-        double tot;
-        double pre = group_excl_scan<G>(d, E.r, tot);
-        double val = base + pre + d;
-        near |= v && (fabs(val - maxd) < 1e-6);
-        Gc += (v && val <= maxd) ? 1 : 0;
-        if (v && val <= maxd) wmax = fmax(wmax, val);
-        base += tot;
-        if (!(base <= maxd)) break;                 // base is group-uniform
+    double base = 0.0, wmax = 0.0; int Gc = 0; bool near = false, small = false;
+    for (int it0 = 0; it0 * G < cnt; it0 += 4) {    // group-uniform trip count; 4 sub-steps per trip so that their
+        float2 cur[4], prev[4];                     // loads are in flight together (one memory round trip per trip)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int i = (it0 + u) * G + E.r;
+            int ic = i < cnt ? i : cnt - 1;
+            cur[u] = tr[n - 2 - ic]; prev[u] = tr[n - 1 - ic];
+        }
+        bool done = false;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int i = (it0 + u) * G + E.r;
+            bool v = i < cnt && !done;
+            double d = v ? euclid_f32(prev[u].x, prev[u].y, cur[u].x, cur[u].y) : 0.0;
+            double tot;
+            double pre = group_excl_scan<G>(d, E.r, tot);
+            double val = base + pre + d;
+            near |= v && (fabs(val - maxd) < 1e-6);
+            small |= v && d != 0.0 && d < kTinySeg;
+            Gc += (v && val <= maxd) ? 1 : 0;
+            if (v && val <= maxd) wmax = fmax(wmax, val);
+            base += tot;
+            if (!(base <= maxd)) done = true;       // base is group-uniform
+        }
+        if (done) break;
     }
     Gc = group_sum<G>(Gc);
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, off, G));
-    if (group_any<G>(near)) {
+    tiny = group_any<G>(small) || maxd > 500.0;
+    if (tiny && group_any<G>(near)) {
         Gc = g_green_seq(tr, n, maxd);
         wmax = 0.0;
         for (int i = 0; i < Gc; i++) { float2 cur = tr[n - 2 - i], prev = tr[n - 1 - i]; wmax += euclid_f32(prev.x, prev.y, cur.x, cur.y); }
@@ -266,21 +283,27 @@ __device__ __forceinline__ int g_closest(const float2* tr, int r, float px, floa
 // `reversed`: the reference enumerates the range from hi-1 down to lo (the green list), ties go to the HIGHER index.
 template <int G>
 __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* bb, int r, float px, float py, int lo, int hi,
-                                               float thr2, bool reversed, float& best, int& bi) {
+                                               float thr2, bool reversed, int init, float init_d2, float& best, int& bi) {
     best = __int_as_float(0x7f800000); bi = 0x7fffffff;
     int key = 0x7fffffff;                                     // enumeration order of the reference (smaller = earlier)
+    float bound = thr2;                                       // blocks farther than this cannot hold the wanted arg-min
+    if (init >= lo && init < hi) {                            // a member of the range whose distance is already known
+        if (r == 0) { best = init_d2; bi = init; key = reversed ? (hi - 1 - init) : init; }   // (from the hint window):
+        bound = fminf(bound, init_d2);                         // it bounds the minimum
+    }
     const int b_lo = lo / FTL_TRAJ_BLOCK, b_hi = (hi - 1) / FTL_TRAJ_BLOCK;
     for (int b0 = b_lo; b0 <= b_hi; b0 += G) {                // group-uniform trip count
         int b = b0 + r;
-        bool cand = false;
+        float bd2 = __int_as_float(0x7f800000);
         if (b <= b_hi) {
             float4 box = bb[b];
             float dx = fmaxf(fmaxf(box.x - px, px - box.z), 0.0f), dy = fmaxf(fmaxf(box.y - py, py - box.w), 0.0f);
-            cand = dx * dx + dy * dy <= thr2;
+            bd2 = dx * dx + dy * dy - 1e-2f;                  // slack far above the float32 rounding of the box test
         }
-        unsigned m = (unsigned)((__ballot(cand) >> (threadIdx.x & ~(G - 1))) & ((1ull << G) - 1ull));
+        unsigned m = (unsigned)((__ballot(bd2 <= bound) >> (threadIdx.x & ~(G - 1))) & ((1ull << G) - 1ull));
         while (m) {                                           // group-uniform: every lane of the group sees the same mask
             int k = __ffs(m) - 1; m &= m - 1;
+            if (!(__shfl(bd2, k, G) <= bound)) continue;      // the bound may have tightened since the mask was formed
             int s0 = (b0 + k) * FTL_TRAJ_BLOCK;
             int i0 = max(s0, lo), i1 = min(s0 + FTL_TRAJ_BLOCK, hi);
 #pragma unroll 8
@@ -291,6 +314,10 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
                 int ky = reversed ? (hi - 1 - i) : i;
                 if (d2 < best || (d2 == best && ky < key)) { best = d2; bi = i; key = ky; }
             }
+            float gbest = best;                               // tighten the bound with what the group has seen so far
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, off, G));
+            bound = fminf(bound, gbest);
         }
     }
     // combine the lanes: smallest d2, then earliest in the reference's enumeration order
@@ -378,43 +405,65 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     }
     // green zone (ENV:968-969): recomputed when a point was appended
     const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)E.env * c.traj_cap * 2);
+#ifndef FTL_ABLATE_GREEN
     if (E.green_len != E.traj_len) {
         // One point was appended since the window was last derived.  The window (ENV:1828-1843: newest segments whose
         // sequential f64 length sum stays <= max_distance) is slid instead of re-walked: add the new segment, drop the
         // oldest ones while the running length exceeds max_distance.  The running length differs from the reference's
-        // sums by rounding only (it is re-derived from scratch every 64 points), so every comparison that is not within
+        // sums by rounding only (< 1e-10 over a whole episode; it is re-derived from scratch every 1024 points anyway), so every comparison that is not within
         // 1e-6 of the threshold is the reference's comparison; otherwise the full walk decides.
         const int nn = E.traj_len;
         const double maxd = c.max_distance;
-        bool exact = (E.green_len != nn - 1) || (nn % 64 == 0) || E.green_count < 1;
-        int Gn = E.green_count; double W = E.green_w;
+        bool exact = (E.green_len != nn - 1) || (nn % 1024 == 0) || E.green_count < 1;
+        int Gn = E.green_count + 1; double W = E.green_w; int tiny = E.green_tiny;
+        const double band = tiny ? 1e-6 : 0.0;            // exact arithmetic (see kTinySeg) needs no tolerance band
         if (!exact) {
+            // everything the slide can need in ONE memory round trip: the two newest points and the four points around
+            // the old end of the window (segments q1-q0 [just beyond], q2-q1 [oldest], q3-q2 [second oldest])
+            const int o = nn - 2 - Gn;
             float2 p1 = tr[nn - 1], p0 = tr[nn - 2];
-            W += euclid_f32(p1.x, p1.y, p0.x, p0.y); Gn += 1;
-            for (int guard = 0; guard < 64 && Gn > 0 && W > maxd; guard++) {
-                if (fabs(W - maxd) < 1e-6) { exact = true; break; }
-                float2 a = tr[nn - Gn], b = tr[nn - 1 - Gn];       // oldest segment of the window
-                W -= euclid_f32(a.x, a.y, b.x, b.y); Gn -= 1;
+            float2 q0 = tr[max(o, 0)], q1 = tr[max(o + 1, 0)], q2 = tr[max(o + 2, 0)], q3 = tr[max(o + 3, 0)];
+            const double d_beyond = euclid_f32(q1.x, q1.y, q0.x, q0.y), d_old1 = euclid_f32(q2.x, q2.y, q1.x, q1.y),
+                         d_old2 = euclid_f32(q3.x, q3.y, q2.x, q2.y);
+            const double d_new = euclid_f32(p1.x, p1.y, p0.x, p0.y);
+            if (d_new != 0.0 && d_new < kTinySeg) { tiny = 1; exact = true; }     // sums stop being exact: re-derive with the band
+            W += d_new;
+            double nxt = d_beyond;                      // length of the segment just beyond the window
+            bool have_nxt = o >= 0;
+            if (W > maxd) {                              // drop the oldest segment
+                if (fabs(W - maxd) < band || Gn < 2) exact = true;
+                W -= d_old1; Gn -= 1; nxt = d_old1; have_nxt = true;
+                if (W > maxd) {                          // and the second oldest
+                    if (fabs(W - maxd) < band || Gn < 2) exact = true;
+                    W -= d_old2; Gn -= 1; nxt = d_old2;
+                    if (W > maxd) exact = true;          // more than two: let the full walk do it
+                }
             }
-            if (!exact && (fabs(W - maxd) < 1e-6 || W > maxd || Gn < 1)) exact = true;
-            if (!exact && Gn < nn - 1) {                            // the segment just beyond the window must stay excluded
-                float2 a = tr[nn - 1 - Gn], b = tr[nn - 2 - Gn];
-                if (!(W + euclid_f32(a.x, a.y, b.x, b.y) > maxd + 1e-6)) exact = true;
-            }
+            if (fabs(W - maxd) < band) exact = true;
+            if (have_nxt && !(W + nxt > maxd + band)) exact = true;     // the segment beyond the window must stay excluded
         }
-        if (exact) Gn = g_green_walk<G>(P, E, W);
-        E.green_count = Gn; E.green_w = W; E.green_len = nn;
+#ifdef FTL_DEBUG_EXACT
+        if (exact) { int why = (E.green_len != nn - 1) ? 1 : (E.green_count < 1 ? 2 : 3); E.error = (E.error & 0xff) | (why << 8) | ((((E.error >> 16) + 1) & 0xffff) << 16); }
+#endif
+#ifndef FTL_ABLATE_EXACT
+        if (exact) Gn = g_green_walk<G>(P, E, W, tiny);
+#endif
+        E.green_count = Gn; E.green_w = W; E.green_len = nn; E.green_tiny = tiny;
     }
+#endif
     const int Gc = E.green_count, n = E.traj_len;
     // _check_agent_position (ENV:1906-1937).  Its two arg-min searches only feed threshold tests: closest green point
     // within epsilon -> on trace + in box; within max_dev -> in box; otherwise closest point of the WHOLE trajectory
     // within epsilon -> on trace.  g_range_argmin() returns the reference's arg-min whenever it matters for such a
     // test; a hint window around the point that was close last frame settles the common on-trace case first.
+#ifndef FTL_ABLATE_AGENT
     if (Gc > 2) {
         const double eps = c.leader_pos_epsilon, mdev = c.max_dev;
         const float4* bb = s_bb;                              // block bounding boxes, staged in LDS for the step
         const int g_lo = n - 1 - Gc;                           // green points are indices g_lo .. n-2
-        float wbest = __int_as_float(0x7f800000); int widx = 0x7fffffff;
+        // hint window: 4*G points around the point that was closest last frame, one memory round trip
+        float wbest = __int_as_float(0x7f800000); int widx = 0x7fffffff;      // over the whole window
+        float gbest = __int_as_float(0x7f800000); int gidx = 0x7fffffff;      // over its green members (ties -> higher index)
         {
             int w0 = E.hint - 2 * G; w0 = w0 < 0 ? 0 : w0;
 #pragma unroll
@@ -425,18 +474,27 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                     float dx = p.x - fpx, dy = p.y - fpy;
                     float d2 = dx * dx + dy * dy;
                     if (d2 < wbest) { wbest = d2; widx = i; }
+                    if (i >= g_lo && i <= n - 2 && d2 <= gbest) { gbest = d2; gidx = i; }
                 }
             }
             group_argmin<G>(wbest, widx);
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) {
+                float ov = __shfl_xor(gbest, off, G); int oi = __shfl_xor(gidx, off, G);
+                bool take = (ov < gbest) || (ov == gbest && oi != 0x7fffffff && (gidx == 0x7fffffff || oi > gidx));
+                if (take) { gbest = ov; gidx = oi; }
+            }
         }
         // "some point is clearly within epsilon" => the arg-min point (smallest float32 squared distance) is too
-        const bool hint_close = wbest < (float)(eps * eps * (1.0 - 1e-5));
-        if (hint_close && widx >= g_lo && widx <= n - 2) {     // a green point is within epsilon
-            E.is_on_trace = 1; E.is_in_box = 1; E.hint = widx;
-        } else {
+        const float eps2_lo = (float)(eps * eps * (1.0 - 1e-5));
+        if (gbest < eps2_lo) {                                 // a green point is within epsilon
+            E.is_on_trace = 1; E.is_in_box = 1; E.hint = gidx;
+        }
+#ifndef FTL_ABLATE_SEARCH
+        else {
             const double far = fmax(mdev, eps);
             float gb2; int gi;
-            g_range_argmin<G>(tr, bb, r, fpx, fpy, g_lo, n - 1, (float)(far * far * (1.0 + 1e-5)) + 1e-2f, true, gb2, gi);
+            g_range_argmin<G>(tr, bb, r, fpx, fpy, g_lo, n - 1, (float)(far * far * (1.0 + 1e-5)) + 1e-2f, true, gidx, gbest, gb2, gi);
             bool in_eps = false, in_dev = false;
             if (gi != 0x7fffffff) {
                 float2 q = tr[gi];
@@ -445,10 +503,10 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             }
             if (in_eps) { E.is_on_trace = 1; E.is_in_box = 1; E.hint = gi; }
             else if (in_dev) { E.is_in_box = 1; E.is_on_trace = 0; E.hint = gi; }
-            else if (hint_close) { E.is_on_trace = 1; E.is_in_box = 0; E.hint = widx; }       // some point is within epsilon
+            else if (wbest < eps2_lo) { E.is_on_trace = 1; E.is_in_box = 0; E.hint = widx; }   // some point is within epsilon
             else {                                             // closest point of the whole trajectory (ENV:1924-1930)
                 float ab2; int ai;
-                g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, ab2, ai);
+                g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, widx, wbest, ab2, ai);
                 if (ai != 0x7fffffff) {
                     float2 q2 = tr[ai];
                     if (euclid_f32_le(fpx, fpy, q2.x, q2.y, eps)) { E.is_on_trace = 1; E.is_in_box = 0; }
@@ -456,7 +514,9 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                 }
             }
         }
+#endif
     }
+#endif
     E.too_close = euclid_f32_le(lpx0, lpy0, fpx, fpy, c.min_distance);
     {   // leader collision (ENV:1068-1072)
         bool out = (double)lpx > (double)c.width || (double)lpy > (double)c.height || lpx < 0.0f || lpy < 0.0f;

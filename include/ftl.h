@@ -182,7 +182,8 @@ enum {
     FTL_EI_SCAN_OK,   /* bit g set: the ray sensors of dict-order group g (before / after the tracker's 2nd scan) scanned this step */
     FTL_EI_SNAP_HEAD, /* ring slot the next snapshot goes to (= snap_count mod max_prev_obs, kept incrementally) */
     FTL_EI_HINT,      /* index of a trajectory point that was close to the follower last frame (search hint only) */
-    FTL_EI_COUNT
+    FTL_EI_GREEN_TINY, /* the green window may hold a segment so short that f64 sums of segment lengths are no longer exact */
+    FTL_EI_PAD, FTL_EI_COUNT
 };
 /* indices into the "env_dbl" state field; bear waypoints follow at FTL_ED_BEAR_POINTS + 2*b */
 enum { FTL_ED_ACC_PENALTY = 0, FTL_ED_OVERALL_REWARD, FTL_ED_SPARE0, FTL_ED_SPARE1, FTL_ED_BEAR_POINTS,
