@@ -115,13 +115,11 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         cur += spec[i].per_env * spec[i].esz * n;
     }
     h->state_bytes = align_up(cur, 256);
-    {   // corridor ring (f32x4) + segment table (f32x4 + u32 mask per entry, worst-case class capacities) + counters
-        const size_t entries = (size_t)(4 * cfg->n_static + 4 * hmax) + (size_t)(4 * hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 4)
-                             + (size_t)2 * cfg->corr_cap + (size_t)2 * hmax;
-        int max_rays = 0;
-        for (int k = 0; k < cfg->n_lasers; k++) max_rays = cfg->lasers[k].count > max_rays ? cfg->lasers[k].count : max_rays;
-        // + ray ends (double2, sized by total_rays) + per-(ray, snapshot) minima (u64 x 8)
-        P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + entries * 20 + 64 + (size_t)rays * 16 + (size_t)max_rays * 8 * 8);
+    {   // corridor ring (f32x4) + near rects (int4 + u32) + corridor refs (u32) + green caps (f32x4 + u32) + counters
+        // + ray ends (double2) + per-(ray, snapshot) minima (u64 x 8)
+        const size_t rects = (size_t)cfg->n_static + hmax + (size_t)hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
+        P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + rects * 20 + (size_t)2 * cfg->corr_cap * 4 + (size_t)2 * hmax * 20 + 64
+                           + (size_t)rays * 16 + (size_t)rays * 8 * 8);
     }
     if (P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
     *out = h;

@@ -317,17 +317,19 @@ __device__ __forceinline__ bool hit_segment(float cx, float cy, double ex, doubl
 }  // namespace ftl
 
 // ---------------------------------------------------------------- kernel 2: the ray casts
-// Phase 1 (lane-parallel): every obstacle segment any sensor of this env could see -- static rect edges, the leader /
-//   bear rect edges of the last H snapshots, the corridor polylines and green-zone caps of those snapshots -- is tested
-//   against the sensors' reach around the follower and the survivors are compacted into a per-class segment table in
-//   LDS (segment f32x4 + bit mask of the snapshots that contain it).  A segment wholly outside the reach box cannot
-//   intersect any ray, so dropping it is exact.
-// Phase 2 (per sensor): ray ends are computed once (one ray per lane) into LDS.  Then one table SEGMENT per lane: the
-//   lane works out which rays can possibly reach its segment -- those whose direction falls inside the arc the segment
-//   subtends at the follower, widened by a slack that dwarfs every rounding error -- and runs the reference's
-//   intersection test only for them (typically 1-4 of the 12/24 rays instead of all).  A hit is folded into the
-//   per-(ray, snapshot) nearest squared distance with a 64-bit LDS atomic min (non-negative doubles order like their
-//   bit patterns); finally one ray per lane turns its H minima into the H output rows.
+// One wavefront per env.  Every phase flattens its work items into one index space so that the 64 lanes stay busy.
+// Phase 1 (one SOURCE per lane): every obstacle any sensor of this env could see -- static rects, the leader / bear
+//   rects of the last H snapshots, the corridor polyline points and green-zone caps of those snapshots -- is tested
+//   against the sensors' reach around the follower; survivors are expanded to segments and compacted into a per-class
+//   table in LDS (segment f32x4 + bit mask of the snapshots that contain it).  A segment wholly outside the reach box
+//   cannot intersect any ray, so dropping it is exact.
+// Phase 2 (one RAY per lane): ray ends of all sensors (sensors.py:888-891) and the per-(ray, snapshot) minima.
+// Phase 3 (one (SENSOR, SEGMENT) pair per lane): the lane works out which rays of that sensor can possibly reach its
+//   segment -- those whose direction falls inside the arc the segment subtends at the follower, widened by a slack that
+//   dwarfs every rounding error -- and runs the reference's intersection test only for them (typically 1-4 of the 12/24
+//   rays).  A hit is folded into the nearest squared distance of (ray, snapshot) with a 64-bit LDS atomic min
+//   (non-negative doubles order like their bit patterns).
+// Phase 4 (one RAY per lane): H minima -> the H output rows of the ray.
 // HM = compile-time number of history accumulators (5 covers every in-repo config, 8 is the ABI cap)
 template <int HM>
 __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
@@ -342,17 +344,21 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     const int hmax = P.hmax;
     const int nrect_dyn = P.R - 1;      // leader + bears per snapshot
     const int cmask = c.corr_cap - 1;   // corr_cap is a power of two (validated on the host)
-    // LDS: f32 corridor ring | segment table (float4) | masks (u32) | class counters
-    const int cap_static = 4 * c.n_static + 4 * hmax, cap_dyn = 4 * hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 4;
-    const int cap_corr = 2 * c.corr_cap, cap_green = 2 * hmax;
-    const int off1 = cap_static, off2 = off1 + cap_dyn, off3 = off2 + cap_corr, off4 = off3 + cap_green;
-    auto cls_off = [&](int q) { return q == 0 ? 0 : (q == 1 ? off1 : (q == 2 ? off2 : off3)); };
+    // LDS: f32 corridor ring | near rects (int4 + mask; static class first region, dynamic class second) | corridor
+    //      segment references (u32) | green caps (f32x4 + mask) | class counters | ray ends | minima.
+    // Rect edges and corridor segments are expanded on the fly in phase 3, so the table stays small (occupancy).
+    const int cap_rs = c.n_static + hmax, cap_rd = hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
+    const int cap_cr = 2 * c.corr_cap, cap_gr = 2 * hmax;
     float4* s_corr = reinterpret_cast<float4*>(lds);
-    float4* s_seg = s_corr + c.corr_cap;
-    unsigned* s_mask = reinterpret_cast<unsigned*>(s_seg + off4);
-    int* s_cnt = reinterpret_cast<int*>(s_mask + off4);
-    double2* s_ray = reinterpret_cast<double2*>(reinterpret_cast<unsigned char*>(s_cnt) + 16);       // [max rays of a sensor]
-    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [rays][HM]
+    int4* s_rect = reinterpret_cast<int4*>(s_corr + c.corr_cap);                 // [cap_rs + cap_rd]
+    float4* s_green = reinterpret_cast<float4*>(s_rect + cap_rs + cap_rd);       // [cap_gr]
+    unsigned* s_rmask = reinterpret_cast<unsigned*>(s_green + cap_gr);           // [cap_rs + cap_rd]
+    unsigned* s_cref = s_rmask + cap_rs + cap_rd;                                // [cap_cr]: p & cmask | side << 15 | mask << 16
+    unsigned* s_gmask = s_cref + cap_cr;                                         // [cap_gr]
+    int* s_cnt = reinterpret_cast<int*>(s_gmask + cap_gr);                       // [SEG_CLASSES]
+    const int n_u32 = (cap_rs + cap_rd) + cap_cr + cap_gr + 4;                   // words since the last 16-byte aligned array
+    double2* s_ray = reinterpret_cast<double2*>(s_rmask + ((n_u32 + 3) & ~3));     // 16-byte aligned [total_rays]
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [total_rays][HM]
     const unsigned long long kInfBits = 0x7fefffffffffffffull;                                       // DBL_MAX: "no hit"
 
     const int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
@@ -398,136 +404,186 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         }
         __syncthreads();
 
-        // ---- phase 1: culled, compacted segment table ------------------------------------------------------------------
+        // ---- phase 1: culled, compacted segment table; sources flattened: statics | snapshot rects | corridor points | caps
         const float reach = lmax + 2.0f;
         const float bx0 = cx - reach, bx1 = cx + reach, by0 = cy - reach, by1 = cy + reach;
-        auto push_rect = [&](int cls, int4 q, unsigned sm) {           // 4 edges in the order of sensors.py:668-671
+        auto push_rect = [&](int cls, int4 q, unsigned sm) {
             if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) return;
-            int at = cls_off(cls) + atomicAdd(&s_cnt[cls], 4);
-            float l = (float)q.x, t = (float)q.y, r = (float)(q.x + q.z), b = (float)(q.y + q.w);
-            s_seg[at] = make_float4(l, b, r, b); s_seg[at + 1] = make_float4(r, t, r, b);
-            s_seg[at + 2] = make_float4(r, t, l, t); s_seg[at + 3] = make_float4(l, b, l, t);
-            s_mask[at] = sm; s_mask[at + 1] = sm; s_mask[at + 2] = sm; s_mask[at + 3] = sm;
+            int at = (cls == SEG_STATIC ? 0 : cap_rs) + atomicAdd(&s_cnt[cls], 1);
+            s_rect[at] = q; s_rmask[at] = sm;
         };
-        auto push_seg = [&](int cls, float ax, float ay, float bx, float by, unsigned sm, bool cull) {
-            if (cull && (fmaxf(ax, bx) < bx0 || fminf(ax, bx) > bx1 || fmaxf(ay, by) < by0 || fminf(ay, by) > by1)) return;
-            int at = cls_off(cls) + atomicAdd(&s_cnt[cls], 1);
-            s_seg[at] = make_float4(ax, ay, bx, by); s_mask[at] = sm;
+        auto push_corr = [&](int p, int side, float ax, float ay, float bx, float by, unsigned sm) {
+            if (fmaxf(ax, bx) < bx0 || fminf(ax, bx) > bx1 || fmaxf(ay, by) < by0 || fminf(ay, by) > by1) return;
+            s_cref[atomicAdd(&s_cnt[SEG_CORRIDOR], 1)] = (unsigned)(p & cmask) | ((unsigned)side << 15) | (sm << 16);
         };
-        {   // static rects straight from the scenario pool: identical in every snapshot
-            const int4* src = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)scen * c.n_static;
-            for (int s = lane; s < c.n_static; s += FTL_WAVE) push_rect(SEG_STATIC, src[s], all_snaps);
-        }
-        {   // leader (a static-class object: it sits in game_object_list) and bears, per snapshot
+        auto push_green = [&](float ax, float ay, float bx, float by, unsigned sm) {
+            if (fmaxf(ax, bx) < bx0 || fminf(ax, bx) > bx1 || fmaxf(ay, by) < by0 || fminf(ay, by) > by1) return;
+            int at = atomicAdd(&s_cnt[SEG_GREEN], 1);
+            s_green[at] = make_float4(ax, ay, bx, by); s_gmask[at] = sm;
+        };
+        {
+            const int n_st = c.n_static, n_dy = nsnap * nrect_dyn, n_co = max(umax - 1 - umin, 0), n_gr = nsnap;
+            const int n_src = n_st + n_dy + n_co + n_gr;
+            const int4* st = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)scen * c.n_static;
             const int4* sr = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)env * hmax * nrect_dyn;
-            for (int i = lane; i < nsnap * nrect_dyn; i += FTL_WAVE) {
-                int a = 0, o = i;
-                while (o >= nrect_dyn) { o -= nrect_dyn; a++; }          // i / nrect_dyn without an integer divide (a < 8)
-                int slot = newest - a; slot += slot < 0 ? hmax : 0;
-                push_rect(o == 0 ? SEG_STATIC : SEG_DYNAMIC, sr[slot * nrect_dyn + o], 1u << a);
+            for (int w = lane; w < n_src; w += FTL_WAVE) {
+                if (w < n_st) {
+                    push_rect(SEG_STATIC, st[w], all_snaps);                  // identical in every snapshot
+                } else if (w < n_st + n_dy) {
+                    // the leader is a static-class object (it sits in game_object_list); bears are the dynamic class
+                    int a = 0, o = w - n_st;
+                    while (o >= nrect_dyn) { o -= nrect_dyn; a++; }
+                    int slot = newest - a; slot += slot < 0 ? hmax : 0;
+                    push_rect(o == 0 ? SEG_STATIC : SEG_DYNAMIC, sr[slot * nrect_dyn + o], 1u << a);
+                } else if (w < n_st + n_dy + n_co) {
+                    // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
+                    int p = umin + (w - n_st - n_dy);
+                    unsigned sm = 0;
+#pragma unroll
+                    for (int a = 0; a < HM; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
+                    if (sm) {
+                        float4 u = s_corr[p & cmask], v = s_corr[(p + 1) & cmask];
+                        push_corr(p, 0, u.x, u.y, v.x, v.y, sm);      // right border
+                        push_corr(p, 1, u.z, u.w, v.z, v.w, sm);      // left border
+                    }
+                } else {
+                    // green-zone end caps of one snapshot (sensors.py:648-650)
+                    int a = w - n_st - n_dy - n_co, lo = 0, hi = 0;
+#pragma unroll
+                    for (int j = 0; j < HM; j++) if (j == a) { lo = win_lo[j]; hi = win_hi[j]; }
+                    float4 u = s_corr[lo & cmask], v = s_corr[(hi - 1) & cmask];
+                    push_green(u.x, u.y, u.z, u.w, 1u << a);
+                    push_green(v.x, v.y, v.z, v.w, 1u << a);
+                }
             }
         }
-        // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
-        for (int p = umin + lane; p + 1 < umax; p += FTL_WAVE) {
-            unsigned sm = 0;
+        // ---- phase 2: ray ends of every sensor of this group + accumulators ------------------------------------------------
+        {
+            int base = 0;
+            for (int k = 0; k < c.n_lasers; k++) {
+                if (c.lasers[k].after_tracker != which) continue;
+                const int N = c.lasers[k].count;
+                const double len = c.lasers[k].length, aoff = c.lasers[k].angle_offset, period = 360.0 / (double)N;
+                for (int i = lane; i < N; i += FTL_WAVE) {
+                    double s, co;
+                    sincos_bounded(((fdir + aoff) + i * period) * kDeg2Rad, s, co);
+                    s_ray[base + i] = make_double2((double)cx + co * len, (double)cy + s * len);
 #pragma unroll
-            for (int a = 0; a < HM; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
-            if (!sm) continue;
-            float4 u = s_corr[p & cmask], v = s_corr[(p + 1) & cmask];
-            push_seg(SEG_CORRIDOR, u.x, u.y, v.x, v.y, sm, true);      // right border
-            push_seg(SEG_CORRIDOR, u.z, u.w, v.z, v.w, sm, true);      // left border
-        }
-        // green-zone end caps of every snapshot (sensors.py:648-650)
-#pragma unroll
-        for (int a = 0; a < HM; a++) if (a < nsnap && lane == a) {
-            float4 u = s_corr[win_lo[a] & cmask], v = s_corr[(win_hi[a] - 1) & cmask];
-            push_seg(SEG_GREEN, u.x, u.y, u.z, u.w, 1u << a, true);
-            push_seg(SEG_GREEN, v.x, v.y, v.z, v.w, 1u << a, true);
+                    for (int j = 0; j < HM; j++) s_best[(base + i) * HM + j] = kInfBits;
+                }
+                base += N;
+            }
         }
         __syncthreads();
 
-        // ---- phase 2: segments x candidate rays per sensor ------------------------------------------------------------------
-#pragma nounroll
-        for (int k = 0; k < c.n_lasers; k++) {
-            if (c.lasers[k].after_tracker != which) continue;
-            const int N = c.lasers[k].count, H = c.lasers[k].history, ooff = c.lasers[k].out_offset;
-            const double len = c.lasers[k].length, aoff = c.lasers[k].angle_offset, period = 360.0 / (double)N;
-            const int ro = c.lasers[k].react_obstacles;
-            unsigned cls_on = 0;          // sensors.py:644-660
-            if (ro == 1 || ro == 2) cls_on |= 1u << SEG_STATIC;
-            if (ro == 1 || ro == 3) cls_on |= 1u << SEG_DYNAMIC;
-            if (c.lasers[k].react_corridor) cls_on |= 1u << SEG_CORRIDOR;
-            if (c.lasers[k].react_green) cls_on |= 1u << SEG_GREEN;
-            __syncthreads();
-            // ray ends (sensors.py:888-891) and accumulators
-            for (int i = lane; i < N; i += FTL_WAVE) {
-                double s, co;
-                sincos_bounded(((fdir + aoff) + i * period) * kDeg2Rad, s, co);
-                s_ray[i] = make_double2((double)cx + co * len, (double)cy + s * len);
-#pragma unroll
-                for (int j = 0; j < HM; j++) s_best[i * HM + j] = kInfBits;
+        // ---- phase 3: (sensor, segment) pairs x candidate rays -----------------------------------------------------------------
+        {
+            // flattened work list: for every sensor of the group the table entries of the classes it reacts to
+            int n_items = 0;
+            for (int k = 0; k < c.n_lasers; k++) {
+                if (c.lasers[k].after_tracker != which) continue;
+                const int ro = c.lasers[k].react_obstacles;
+                if (ro == 1 || ro == 2) n_items += 4 * s_cnt[SEG_STATIC];      // 4 edges per rect
+                if (ro == 1 || ro == 3) n_items += 4 * s_cnt[SEG_DYNAMIC];
+                if (c.lasers[k].react_corridor) n_items += s_cnt[SEG_CORRIDOR];
+                if (c.lasers[k].react_green) n_items += s_cnt[SEG_GREEN];
             }
-            __syncthreads();
-            // direction of ray 0 and ray spacing in radians, float32 (candidate selection only)
-            const float phi0 = (float)(((fdir + aoff)) * kDeg2Rad), inv_step = (float)((double)N / 6.283185307179586);
-            const float reachf = (float)len + 2.0f;
-#pragma nounroll
-            for (int q = 0; q < SEG_CLASSES; q++) {
-                if (!((cls_on >> q) & 1u)) continue;
-                const int beg = cls_off(q), end = beg + s_cnt[q];
-                for (int m = beg + lane; m < end; m += FTL_WAVE) {
-                    const float4 sg = s_seg[m];
-                    const unsigned sm = s_mask[m];
+            for (int w0 = 0; w0 < n_items; w0 += FTL_WAVE) {
+                const int w = w0 + lane;
+                // decode w -> (sensor k, class q, index m within the class); per-lane sensor parameters
+                int m = -1, mq = 0, N = 1, rbase = 0; float lenf = 0.0f, phi0 = 0.0f;
+                {
+                    int rem = w, rb = 0;
+                    for (int k = 0; k < c.n_lasers; k++) {
+                        if (c.lasers[k].after_tracker != which) continue;
+                        const int ro = c.lasers[k].react_obstacles;
+                        const bool on[SEG_CLASSES] = { ro == 1 || ro == 2, ro == 1 || ro == 3, c.lasers[k].react_corridor != 0, c.lasers[k].react_green != 0 };
+#pragma unroll
+                        for (int q = 0; q < SEG_CLASSES; q++) {
+                            const int cq = on[q] ? (q < 2 ? 4 * s_cnt[q] : s_cnt[q]) : 0;
+                            if (m < 0 && rem >= 0 && rem < cq && w < n_items) {
+                                m = rem; mq = q; N = c.lasers[k].count; rbase = rb; lenf = (float)c.lasers[k].length;
+                                phi0 = (float)((fdir + c.lasers[k].angle_offset) * kDeg2Rad);
+                            }
+                            rem -= cq;
+                        }
+                        rb += c.lasers[k].count;
+                    }
+                }
+                int i0 = 0, cnt = 0;
+                float4 sg = make_float4(0.f, 0.f, 0.f, 0.f); unsigned sm = 0;
+                const float fN = (float)N;
+                if (m >= 0) {
+                    if (mq < 2) {                                // edge (m & 3) of a near rect, in the order of sensors.py:668-671
+                        const int at = (mq == SEG_STATIC ? 0 : cap_rs) + (m >> 2);
+                        const int4 q = s_rect[at]; sm = s_rmask[at];
+                        const float l = (float)q.x, t = (float)q.y, r = (float)(q.x + q.z), b = (float)(q.y + q.w);
+                        const int e = m & 3;
+                        sg = e == 0 ? make_float4(l, b, r, b) : e == 1 ? make_float4(r, t, r, b) : e == 2 ? make_float4(r, t, l, t) : make_float4(l, b, l, t);
+                    } else if (mq == SEG_CORRIDOR) {             // polyline segment p -> p+1 of the right (0) / left (1) border
+                        const unsigned ref = s_cref[m];
+                        const int p = ref & 0x7fff; sm = ref >> 16;
+                        const float4 u = s_corr[p], v = s_corr[(p + 1) & cmask];
+                        sg = (ref >> 15) & 1u ? make_float4(u.z, u.w, v.z, v.w) : make_float4(u.x, u.y, v.x, v.y);
+                    } else { sg = s_green[m]; sm = s_gmask[m]; }
                     // candidate rays: the arc [uA, uB] the segment subtends, in units of the ray spacing from ray 0
+                    const float inv_step = fN * 0.15915494309189535f;          // N / (2 pi)
                     float ax = sg.x - cx, ay = sg.y - cy, bx = sg.z - cx, by = sg.w - cy;
                     float uA = (atan2f(ay, ax) - phi0) * inv_step, uB = (atan2f(by, bx) - phi0) * inv_step;
-                    const float fN = (float)N;
                     uA -= floorf(uA / fN) * fN; uB -= floorf(uB / fN) * fN;          // into [0, N)
                     float diff = uB - uA; if (diff < 0.0f) diff += fN;
-                    float start = uA, w = diff;
-                    if (diff > 0.5f * fN) { start = uB; w = fN - diff; }
-                    // closest approach of the segment's line to the follower: an arc is only meaningful if it is not tiny
+                    float start = uA, wd = diff;
+                    if (diff > 0.5f * fN) { start = uB; wd = fN - diff; }
+                    // closest approach of the segment to the follower
                     float ex_ = bx - ax, ey_ = by - ay;
                     float l2 = ex_ * ex_ + ey_ * ey_;
                     float tt = l2 > 0.0f ? fminf(fmaxf(-(ax * ex_ + ay * ey_) / l2, 0.0f), 1.0f) : 0.0f;
                     float nx = ax + tt * ex_, ny = ay + tt * ey_;
                     float dmin2 = nx * nx + ny * ny;
-                    int i0, cnt;
-                    if (dmin2 < 4.0f || w > 0.5f * fN - 0.05f) { i0 = 0; cnt = N; }       // through / next to the origin: every ray
-                    else if (dmin2 > reachf * reachf) { i0 = 0; cnt = 0; }                 // wholly beyond this sensor's reach
+                    const float reachf = lenf + 2.0f;
+                    if (dmin2 < 4.0f || wd > 0.5f * fN - 0.05f) { i0 = 0; cnt = N; }      // through / next to the origin: every ray
+                    else if (dmin2 > reachf * reachf) { i0 = 0; cnt = 0; }                // wholly beyond this sensor's reach
                     else {
-                        const float slack = 0.02f + 0.01f * fN / 6.2831853f;               // >= 0.01 rad, far above float error
+                        const float slack = 0.02f + 0.01f * fN * 0.15915494f;             // >= 0.01 rad, far above float error
                         i0 = (int)ceilf(start - slack);
-                        cnt = (int)floorf(start + w + slack) - i0 + 1;
+                        cnt = (int)floorf(start + wd + slack) - i0 + 1;
                         cnt = cnt > N ? N : cnt;
                     }
-                    for (int t = 0; t < cnt; t++) {
-                        int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
-                        const double2 e = s_ray[i];
-                        double d2;
-                        if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sg, d2)) {
-                            const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
+                }
+                for (int t = 0; t < cnt; t++) {
+                    int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
+                    const double2 e = s_ray[rbase + i];
+                    double d2;
+                    if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sg, d2)) {
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
 #pragma unroll
-                            for (int j = 0; j < HM; j++) if ((sm >> j) & 1u) atomicMin(&s_best[i * HM + j], bits);
-                        }
+                        for (int j = 0; j < HM; j++) if ((sm >> j) & 1u) atomicMin(&s_best[(rbase + i) * HM + j], bits);
                     }
                 }
             }
-            __syncthreads();
-            // rows: oldest first, newest last (sensors.py:896-901); rows older than the first scan and rays without a
-            // hit read |end - origin| (sensors.py:925-930)
-            for (int i = lane; i < N; i += FTL_WAVE) {
-                const double2 e = s_ray[i];
-                double qx0 = e.x - (double)cx, qy0 = e.y - (double)cy;
-                const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
+        }
+        __syncthreads();
+        // ---- phase 4: rows, oldest first, newest last (sensors.py:896-901); rows older than the first scan and rays without a
+        // hit read |end - origin| (sensors.py:925-930)
+        {
+            int base = 0;
+            for (int k = 0; k < c.n_lasers; k++) {
+                if (c.lasers[k].after_tracker != which) continue;
+                const int N = c.lasers[k].count, H = c.lasers[k].history, ooff = c.lasers[k].out_offset;
+                for (int i = lane; i < N; i += FTL_WAVE) {
+                    const double2 e = s_ray[base + i];
+                    double qx0 = e.x - (double)cx, qy0 = e.y - (double)cy;
+                    const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
 #pragma unroll
-                for (int a2 = 0; a2 < HM; a2++) {
-                    if (a2 < H) {
-                        unsigned long long b = s_best[i * HM + a2];
-                        double v = (a2 < nsnap && b != kInfBits) ? sqrt(__longlong_as_double((long long)b)) : miss;
-                        out_base[ooff + (H - 1 - a2) * N + i] = (float)v;
+                    for (int a2 = 0; a2 < HM; a2++) {
+                        if (a2 < H) {
+                            unsigned long long b = s_best[(base + i) * HM + a2];
+                            double v = (a2 < nsnap && b != kInfBits) ? sqrt(__longlong_as_double((long long)b)) : miss;
+                            out_base[ooff + (H - 1 - a2) * N + i] = (float)v;
+                        }
                     }
                 }
+                base += N;
             }
         }
     }
