@@ -36,7 +36,12 @@ class LaserSpec:
     history: int
     angle_offset: float
     after_tracker: bool
+    pad_sectors: bool = False
     out_offset: int = 0
+
+    @property
+    def width(self):            # row width of the sensor's output block (SEN:932-958)
+        return 4 * self.count if self.pad_sectors else self.count
 
 
 @dataclass
@@ -60,7 +65,7 @@ class GameConfig:
 
     @property
     def lasers_len(self):
-        return sum(l.history * l.count for l in self.lasers)
+        return sum(l.history * l.width for l in self.lasers)
 
 
 def _react_code(v):
@@ -237,16 +242,13 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
                 raise ValueError("Invalid number of laser beams, should be 12,24,20 or 36")  # SEN:761-762
             hist = spec.get("max_prev_obs", 0)
             assert hist > 0  # SEN:876
-            if spec.get("pad_sectors", True):
-                raise NotImplementedError("pad_sectors=True output layout (SEN:932-953) is scheduled next; "
-                                          "pass pad_sectors=False")
             lasers.append(LaserSpec(name=name, count=n, length=float(spec.get("laser_length", 100)),
                                     react_corridor=bool(spec.get("react_to_safe_corridor", True)),
                                     react_green=bool(spec.get("react_to_green_zone", False)),
                                     react_obstacles=_react_code(spec.get("react_to_obstacles", False)),
                                     history=int(hist),
                                     angle_offset=float(spec.get("first_laser_angle_offset", -45)),
-                                    after_tracker=seen_tracker))
+                                    after_tracker=seen_tracker, pad_sectors=bool(spec.get("pad_sectors", True))))
     if lasers and not c.has_tracker:
         raise NotImplementedError("ray sensors need LeaderPositionsTracker_v2 (reference: NameError on "
                                   "`leader_corridor`, CLS:280)")
@@ -260,7 +262,8 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
         lc.count, lc.length, lc.history = l.count, l.length, l.history
         lc.react_corridor, lc.react_green, lc.react_obstacles = int(l.react_corridor), int(l.react_green), l.react_obstacles
         lc.angle_offset, lc.after_tracker, lc.out_offset = l.angle_offset, int(l.after_tracker), off
-        off += l.history * l.count
+        lc.pad_sectors = int(l.pad_sectors)
+        off += l.history * l.width
 
     # ---- capacities ---------------------------------------------------------------------------------
     # leader_factual_trajectory: initial int(dist/(5*v)) points, dist < 0.9*max_distance, then one point per

@@ -95,11 +95,16 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     int off = 0, hmax = 1, rays = 0;
     for (int k = 0; k < cfg->n_lasers; k++) {
         P.cfg.lasers[k].out_offset = off;
-        off += cfg->lasers[k].history * cfg->lasers[k].count;
+        off += cfg->lasers[k].history * cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1);
         hmax = cfg->lasers[k].history > hmax ? cfg->lasers[k].history : hmax;
         P.rays_k[k] = rays; rays += cfg->lasers[k].count;
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
+    {   // row width / common history of the fused sensorPrev output
+        int w = 0, hcommon = cfg->n_lasers ? cfg->lasers[0].history : 0;
+        for (int k = 0; k < cfg->n_lasers; k++) { P.pol_off[k] = w; w += cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1); if (cfg->lasers[k].history != hcommon) hcommon = -1; }
+        P.pol_width = w; P.pol_h = hcommon;
+    }
     // state layout: one region per field, [n_envs][per_env], 256-byte aligned
     const size_t n = (size_t)n_envs;
     struct { const char* name; size_t per_env; int dtype; size_t esz; } spec[11] = {
@@ -224,6 +229,7 @@ int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const
     if (!h->have_scen) return fail(FTL_E_STATE, "ftl_load_scenarios has not been called");
     int rc = check_out(h, out);
     if (rc) return rc;
+    if (out->policy_obs && h->P.pol_h <= 0) return fail(FTL_E_INVALID, "policy_obs needs the same max_prev_obs on every ray sensor");
     FtlCall call; call.mode = 1; call.scen_idx = scen_idx; call.mask = mask; call.out = *out; call.action = nullptr; call.flags = 0;
     return launch(h, call, stream);
 }
@@ -234,6 +240,7 @@ int ftl_step(ftl_handle* h, const double* action, const ftl_outputs* out, uint32
     if (!h->have_scen) return fail(FTL_E_STATE, "ftl_load_scenarios has not been called");
     int rc = check_out(h, out);
     if (rc) return rc;
+    if (out->policy_obs && h->P.pol_h <= 0) return fail(FTL_E_INVALID, "policy_obs needs the same max_prev_obs on every ray sensor");
     FtlCall call; call.mode = 0; call.action = action; call.out = *out; call.flags = flags; call.scen_idx = nullptr; call.mask = nullptr;
     return launch(h, call, stream);
 }

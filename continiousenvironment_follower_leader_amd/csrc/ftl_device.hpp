@@ -33,13 +33,14 @@
 #define FTL_FRAMES_WPE 3    // min waves per SIMD the register allocator must leave room for (tuned on MI355X)
 #endif
 #ifndef FTL_RAYS_WPE
-#define FTL_RAYS_WPE 4
+#define FTL_RAYS_WPE 6
 #endif
 
 struct FtlDevParams {
     ftl_config cfg;
     int32_t n_envs, R, lasers_len, total_rays, hmax, lds_frames, lds_rays;
     int32_t rays_k[FTL_MAX_LASERS];   // first global ray id of sensor k
+    int32_t pol_off[FTL_MAX_LASERS], pol_width, pol_h;   // fused sensorPrev output: column offset per sensor, row width, common history
     // per-env state (views into the caller-owned state buffer), all [n_envs][...]
     float* rb_pos; double* rb_dbl; int32_t* rb_int; int32_t* env_int; double* env_dbl;
     float* traj; double* hist; double* corr; int32_t* snap_rects; int32_t* snap_win;
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         if (n_sens == 0) continue;
         if (!((scan_ok >> which) & 1)) {       // sensors.py:893/962: the reference raises UnboundLocalError here
             for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which)
-                for (int i = lane; i < c.lasers[k].history * c.lasers[k].count; i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = (float)c.lasers[k].length;
+                for (int i = lane; i < c.lasers[k].history * c.lasers[k].count * (c.lasers[k].pad_sectors ? 4 : 1); i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = (float)c.lasers[k].length;
             continue;
         }
         // corridor windows of the valid snapshots as this group of sensors saw them; age a = 0 newest
@@ -564,22 +565,44 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         }
         __syncthreads();
         // ---- phase 4: rows, oldest first, newest last (sensors.py:896-901); rows older than the first scan and rays without a
-        // hit read |end - origin| (sensors.py:925-930)
+        // hit read |end - origin| (sensors.py:925-930).  pad_sectors (sensors.py:932-953) spreads a row over four N-wide
+        // sector blocks; the optional fused ContinuousObserveModifier_sensorPrev output (wrappers.py:200-221) is
+        // clip(x / laser_length, 0, 1) in float32, sensors concatenated along the row.
         {
+            float* pol = C.out.policy_obs ? C.out.policy_obs + (size_t)env * P.pol_h * P.pol_width : nullptr;
+            bool any_pad = false;
+            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which && c.lasers[k].pad_sectors) {
+                any_pad = true;
+                const int tot = c.lasers[k].history * 4 * c.lasers[k].count;
+                for (int i = lane; i < tot; i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = 0.0f;
+                if (pol) for (int i = lane; i < tot; i += FTL_WAVE) {
+                    int row = i / (4 * c.lasers[k].count), col = i - row * 4 * c.lasers[k].count;
+                    pol[row * P.pol_width + P.pol_off[k] + col] = 0.0f;
+                }
+            }
+            if (any_pad) __syncthreads();
             int base = 0;
             for (int k = 0; k < c.n_lasers; k++) {
                 if (c.lasers[k].after_tracker != which) continue;
                 const int N = c.lasers[k].count, H = c.lasers[k].history, ooff = c.lasers[k].out_offset;
+                const bool pad = c.lasers[k].pad_sectors != 0;
+                const int Wd = pad ? 4 * N : N;
+                const float flen = (float)c.lasers[k].length;           // python number / float32 array -> float32 division
+                const double lis = (double)N / 4.0;                     // lasers_in_sector (sensors.py:938)
                 for (int i = lane; i < N; i += FTL_WAVE) {
                     const double2 e = s_ray[base + i];
                     double qx0 = e.x - (double)cx, qy0 = e.y - (double)cy;
                     const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
+                    int col = i;
+                    if (pad) { const double di = (double)i; col = (di < lis ? 0 : (di < 2 * lis ? 1 : (di < 3 * lis ? 2 : 3))) * N + i; }
 #pragma unroll
                     for (int a2 = 0; a2 < HM; a2++) {
                         if (a2 < H) {
                             unsigned long long b = s_best[(base + i) * HM + a2];
                             double v = (a2 < nsnap && b != kInfBits) ? sqrt(__longlong_as_double((long long)b)) : miss;
-                            out_base[ooff + (H - 1 - a2) * N + i] = (float)v;
+                            const float vf = (float)v;
+                            out_base[ooff + (H - 1 - a2) * Wd + col] = vf;
+                            if (pol) pol[(H - 1 - a2) * P.pol_width + P.pol_off[k] + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
                         }
                     }
                 }

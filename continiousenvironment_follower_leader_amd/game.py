@@ -132,5 +132,7 @@ class Game:
             if cls == "LeaderPositionsTracker_v2":
                 obs[name] = v.tracker_obs(0)            # (leader_positions_hist, corridor), SEN:324-325
             else:
-                obs[name] = v.laser_view(name)[0].cpu().numpy().copy()   # [max_prev_obs, lasers_count] float32, SEN:958
+                a = v.laser_view(name)[0].cpu().numpy().copy()            # [max_prev_obs, lasers_count] float32, SEN:958
+                spec = next(l for l in self.cfg.lasers if l.name == name)
+                obs[name] = a.astype(np.float64) if spec.pad_sectors else a   # pad_sectors rows are float64 (SEN:933-953)
         return obs

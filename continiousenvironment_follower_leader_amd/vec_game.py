@@ -76,7 +76,7 @@ class VecGame:
     ``[H_k, N_k]`` block per ray sensor, ``laser_view(name)``), ``target`` f64[N,2], ``reward`` f64[N],
     ``done`` u8[N], ``status`` u8[N,3] (mission/agent/leader codes of ``abi.MISSION/AGENT/LEADER``)."""
 
-    def __init__(self, n_envs, device="cuda:0", config: GameConfig = None, **game_kwargs):
+    def __init__(self, n_envs, device="cuda:0", config: GameConfig = None, policy_obs=False, **game_kwargs):
         self.cfg = config if config is not None else make_config(**game_kwargs)
         self.n = int(n_envs)
         self.device = torch.device(device)
@@ -104,6 +104,14 @@ class VecGame:
         o = abi.Outputs()
         o.obs_num, o.lasers, o.target = self.obs_num.data_ptr(), self.lasers.data_ptr(), self.target.data_ptr()
         o.reward, o.done, o.status = self.reward.data_ptr(), self.done.data_ptr(), self.status.data_ptr()
+        # fused ContinuousObserveModifier_sensorPrev output (wrappers.py:169-221): [n, H, sum of row widths], float32
+        hs = {l.history for l in self.cfg.lasers}
+        self.policy_obs = None
+        if policy_obs and self.cfg.lasers:
+            if len(hs) != 1:
+                raise ValueError("policy_obs needs the same max_prev_obs on every ray sensor (wrappers.py:214-215 asserts it)")
+            self.policy_obs = torch.zeros(self.n, hs.pop(), sum(l.width for l in self.cfg.lasers), dtype=torch.float32, **z)
+            o.policy_obs = self.policy_obs.data_ptr()
         self._out = o
         self.pool = None
         self._fields = {}
@@ -158,7 +166,7 @@ class VecGame:
     def laser_view(self, name):
         for l in self.cfg.lasers:
             if l.name == name:
-                return self.lasers[:, l.out_offset:l.out_offset + l.history * l.count].view(self.n, l.history, l.count)
+                return self.lasers[:, l.out_offset:l.out_offset + l.history * l.width].view(self.n, l.history, l.width)
         raise KeyError(name)
 
     def state_field(self, name):

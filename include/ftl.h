@@ -71,8 +71,8 @@ typedef struct ftl_laser_cfg {
     int32_t react_obstacles;  /* 0 False, 1 True/"all", 2 "static", 3 "dynamic" (SEN:651-660) */
     int32_t history;          /* max_prev_obs (rows of the output) */
     int32_t after_tracker;    /* 1: scanned after the tracker's 2nd scan of the step (dict order, CLS:269-286) */
-    int32_t out_offset;       /* filled by the library: offset of this sensor's [history][count] block in `lasers` */
-    int32_t _pad;
+    int32_t out_offset;       /* filled by the library: offset of this sensor's [history][width] block in `lasers` */
+    int32_t pad_sectors;      /* SEN:932-953: rows are [front|right|behind|left], 4*count wide, zeros outside a ray's sector */
     double length;            /* laser_length, px */
     double angle_offset;      /* first_laser_angle_offset, deg */
 } ftl_laser_cfg;
@@ -129,11 +129,15 @@ typedef struct ftl_scenarios {
 /* step()/reset() outputs = (obs, reward, done, info) of ENV:945 for n envs, device arrays */
 typedef struct ftl_outputs {
     float*   obs_num;    /* [n][10]            numerical_features (ENV:1793-1802) */
-    float*   lasers;     /* [n][lasers_len]    per sensor k a [history_k][count_k] block at lasers[k].out_offset */
+    float*   lasers;     /* [n][lasers_len]    per sensor k a [history_k][width_k] block at lasers[k].out_offset,
+                            width_k = count_k (4*count_k with pad_sectors) */
     double*  target;     /* [n][2]             leader_target_point (ENV:1803-1806) */
     double*  reward;     /* [n]                last-frame reward (ENV:935-936, 1136-1141) */
     uint8_t* done;       /* [n] */
     uint8_t* status;     /* [n][3]             mission / agent / leader status codes */
+    float*   policy_obs; /* optional (may be NULL): [n][H][sum_k width_k] = ContinuousObserveModifier_sensorPrev.observation
+                            (utils/wrappers.py:200-221): per sensor clip(x / laser_length, 0, 1), concatenated along axis 1;
+                            requires every ray sensor to have the same history H */
 } ftl_outputs;
 
 typedef struct ftl_handle ftl_handle;

@@ -77,6 +77,8 @@ typedef struct ftlo_env {
 
 /* ------------------------------------------------------------------ helpers */
 
+static int laser_width(const ftl_laser_cfg* L) { return L->pad_sectors ? 4 * L->count : L->count; } /* SEN:932-958 */
+
 /* scipy.spatial.distance.euclidean on two float32 points */
 static double euclid_f32(float ax, float ay, float bx, float by) {
     float dx = ax - bx, dy = ay - by;
@@ -586,9 +588,10 @@ static double seg_hit_distance(const seg_t* s, float cx, float cy, double ex, do
 static void laser_scan(ftlo_env* e, int k, float* out) {
     const ftl_laser_cfg* L = &e->cfg.lasers[k];
     const robot_t* f = &e->rb[1];
-    int N = L->count, H = L->history;
+    int N = L->count, H = L->history, W = laser_width(L);
     double period = 360.0 / N;
-    if (e->corr_len <= 1) { e->error |= FTL_ERR_EMPTY_CORRIDOR; for (int i = 0; i < H * N; i++) out[i] = (float)L->length; return; }
+    if (e->corr_len <= 1) { e->error |= FTL_ERR_EMPTY_CORRIDOR; for (int i = 0; i < H * W; i++) out[i] = (float)L->length; return; }
+    if (L->pad_sectors) for (int i = 0; i < H * W; i++) out[i] = 0.0f;   /* np.zeros sector rows, SEN:933-936 */
     /* SEN:896-897 */
     snapshot_t* hs = e->snaps[k];
     free(hs[0].segs);
@@ -607,7 +610,14 @@ static void laser_scan(ftlo_env* e, int k, float* out) {
                         if (!found || d < best) { best = d; bx = x; by = y; found = 1; } /* argmin: first minimum */
                     }
             double qx = bx - (double)f->px, qy = by - (double)f->py;
-            out[j * N + i] = (float)sqrt(fma(qy, qy, qx * qx));                   /* SEN:930 np.linalg.norm 1-D */
+            float val = (float)sqrt(fma(qy, qy, qx * qx));                         /* SEN:930 np.linalg.norm 1-D */
+            int col = i;
+            if (L->pad_sectors) {                                                   /* SEN:938-953 */
+                double lis = (double)N / 4;
+                int sector = ((double)i < lis) ? 0 : ((double)i < 2 * lis) ? 1 : ((double)i < 3 * lis) ? 2 : 3;
+                col = sector * N + i;
+            }
+            out[j * W + col] = val;
         }
     }
 }
@@ -633,13 +643,13 @@ static void get_obs(const ftlo_env* e, float* obs_num, double* target) {
 
 /* ------------------------------------------------------------------ public (ctypes) API */
 
-int ftlo_lasers_len(const ftl_config* c) { int n = 0; for (int k = 0; k < c->n_lasers; k++) n += c->lasers[k].history * c->lasers[k].count; return n; }
+int ftlo_lasers_len(const ftl_config* c) { int n = 0; for (int k = 0; k < c->n_lasers; k++) n += c->lasers[k].history * laser_width(&c->lasers[k]); return n; }
 
 ftlo_env* ftlo_create(const ftl_config* cfg) {
     ftlo_env* e = (ftlo_env*)calloc(1, sizeof(ftlo_env));
     e->cfg = *cfg;
     int off = 0;
-    for (int k = 0; k < cfg->n_lasers; k++) { e->cfg.lasers[k].out_offset = off; off += cfg->lasers[k].history * cfg->lasers[k].count; }
+    for (int k = 0; k < cfg->n_lasers; k++) { e->cfg.lasers[k].out_offset = off; off += cfg->lasers[k].history * laser_width(&cfg->lasers[k]); }
     e->lasers_len = off;
     e->R = 2 + cfg->n_bears;
     e->srect = (int32_t*)calloc((size_t)(cfg->n_static > 0 ? cfg->n_static : 1) * 4, sizeof(int32_t));

@@ -81,7 +81,7 @@ class OracleEnv:
     def _obs(self):
         out = {"num": self.obs_num.copy(), "target": self.target.copy()}
         for l in self.cfg.lasers:
-            out[l.name] = self.lasers[l.out_offset:l.out_offset + l.history * l.count].reshape(l.history, l.count).copy()
+            out[l.name] = self.lasers[l.out_offset:l.out_offset + l.history * l.width].reshape(l.history, l.width).copy()
         return out
 
     def step(self, action):

@@ -74,6 +74,12 @@ CONFIGS = {
     "B_short": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B, max_steps=450, warm_start=100), post=None),
     # no dynamic obstacles (add_bear=False): long clean episodes -> "success" (ENV:1077-1087)
     "B_nobear": dict(kwargs=dict(add_bear=False, follower_sensors=SENSORS_B), post=None),
+    # pad_sectors=True output layout (SEN:932-953) on the 12-ray sensor, tracker LAST in the dict (as in
+    # server/config/3c1bc/params.json:26-60: the ray sensors are scanned BEFORE the tracker's second scan)
+    "B_pad": dict(kwargs=dict(bear_number=2, follower_sensors=OrderedDict([
+        ("LeaderCorridor_lasers_all", dict(SENSORS_B["LeaderCorridor_lasers_all"], pad_sectors=True)),
+        ("LeaderCorridor_lasers_obstacles", dict(SENSORS_B["LeaderCorridor_lasers_obstacles"], lasers_count=20, react_to_obstacles="dynamic")),
+        ("LeaderPositionsTracker_v2", dict(SENSORS_B["LeaderPositionsTracker_v2"]))])), post=None),
     # three bears (odd index -> _move_bear_v4), sensors of B
     "B3": dict(kwargs=dict(bear_number=3, follower_sensors=SENSORS_B), post=None),
 }
@@ -317,6 +323,7 @@ EPISODES = [
     ("Bnobear_s1_chase", "B_nobear", 1, "chase", 520),
     ("Bnobear_s2_chase", "B_nobear", 2, "chase", 520),
     ("Bnobear_s5_chase", "B_nobear", 5, "chase", 520),
+    ("Bpad_s4_chase", "B_pad", 4, "chase", 150),
 ]
 
 
