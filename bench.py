@@ -79,8 +79,8 @@ def cpu_baseline(cfg, pool_path, n_envs, steps, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=4096)
@@ -177,7 +177,7 @@ def main():
                        "episodes_finished": float(metrics[0].item()), "env_error_flags": float(metrics[2].item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ftl_frames_kernel + ftl_rays_kernel (one step = both launches, same stream)",
+                         "kernel": "ftl_frames_group_kernel<4> + ftl_rays_kernel<5> (one step = both launches, same stream)",
                          "kernel_ms": kernel_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP},
         }
         if world == 1 and not a.no_cpu_baseline:
