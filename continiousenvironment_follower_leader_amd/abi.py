@@ -7,6 +7,7 @@ import ctypes as C
 FTL_ABI_VERSION = 1
 FTL_MAX_BEARS = 4
 FTL_MAX_LASERS = 4
+FTL_MAX_REGIME = 16
 FTL_OBS_NUM = 10
 
 FTL_OK = 0
@@ -23,11 +24,12 @@ FTL_STEP_AUTO_RESET = 1
 (EI_SCEN, EI_TARGET_ID, EI_LEADER_FINISHED, EI_DONE, EI_CRASH, EI_IN_BOX, EI_ON_TRACE, EI_TOO_CLOSE,
  EI_STEP_COUNT, EI_FINISH_TIMER, EI_TRAJ_LEN, EI_TRK_COUNTER, EI_CORR_LO, EI_CORR_HI, EI_SEED_END,
  EI_SNAP_COUNT, EI_DYN_INDEX0, EI_DYN_INDEX1, EI_DYN_INDEX2, EI_DYN_INDEX3, EI_ERROR, EI_EPISODES,
- EI_GREEN_COUNT, EI_GREEN_LEN, EI_SCAN_OK, EI_SNAP_HEAD, EI_HINT, EI_GREEN_TINY, EI_PAD, EI_COUNT) = range(30)
+ EI_GREEN_COUNT, EI_GREEN_LEN, EI_SCAN_OK, EI_SNAP_HEAD, EI_HINT, EI_GREEN_TINY, EI_RESETS, EI_ACC_CONSUMED, EI_PAD,
+ EI_COUNT) = range(32)
 ED_ACC_PENALTY, ED_OVERALL_REWARD, ED_SPARE0, ED_SPARE1, ED_BEAR_POINTS = range(5)
 ED_GREEN_W = ED_BEAR_POINTS + 2 * FTL_MAX_BEARS
-ED_PAD = ED_GREEN_W + 1
-ED_COUNT = ED_PAD + 1
+ED_CUR_MULT, ED_CUR_ACC, ED_CUM_SPEED = ED_GREEN_W + 1, ED_GREEN_W + 2, ED_GREEN_W + 3
+ED_COUNT = ED_CUM_SPEED + 1
 RD_DIRECTION, RD_SPEED, RD_ROT_SPEED, RD_DES_SPEED, RD_DES_ROT_SPEED, RD_COUNT = range(6)
 RI_X, RI_Y, RI_W, RI_H, RI_ROT_DIR, RI_DES_ROT_DIR, RI_SPARE0, RI_SPARE1, RI_COUNT = range(9)
 
@@ -62,7 +64,29 @@ class Config(C.Structure):
                 ("not_on_track_penalty", C.c_double), ("crash_penalty", C.c_double),
                 ("too_close_penalty", C.c_double), ("leader_movement_reward", C.c_double),
                 ("leader", RobotParams), ("follower", RobotParams), ("bear", RobotParams),
-                ("lasers", LaserCfg * FTL_MAX_LASERS)]
+                ("lasers", LaserCfg * FTL_MAX_LASERS),
+                ("n_speed_regime", C.c_int32), ("n_acc_regime", C.c_int32),
+                ("speed_key", C.c_int32 * FTL_MAX_REGIME), ("speed_is_range", C.c_int32 * FTL_MAX_REGIME),
+                ("acc_key", C.c_int32 * FTL_MAX_REGIME), ("env_id_base", C.c_int32), ("_pad1", C.c_int32),
+                ("speed_lo", C.c_double * FTL_MAX_REGIME), ("speed_hi", C.c_double * FTL_MAX_REGIME),
+                ("acc_val", C.c_double * FTL_MAX_REGIME), ("rng_seed", C.c_uint64)]
+
+
+_M64 = (1 << 64) - 1
+
+
+def mix64(x):
+    x &= _M64
+    x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & _M64
+    x ^= x >> 27; x = (x * 0x94D049BB133111EB) & _M64
+    x ^= x >> 31
+    return x
+
+
+def uniform01(rng_seed, env_id, resets, frame):
+    """Python twin of ftl_uniform01() in include/ftl.h (the stream that replaces random.uniform at ENV:1156)."""
+    key = mix64(rng_seed + 0x9E3779B97F4A7C15 * (env_id + 1)) ^ mix64(0xD1B54A32D192ED03 * (resets + 1))
+    return (mix64(key + 0x9E3779B97F4A7C15 * (frame + 1)) >> 11) * (1.0 / 9007199254740992.0)
 
 
 class Scenarios(C.Structure):

@@ -103,6 +103,8 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
                 path_finding_iterations=15000, leader_margin=1.5,
                 # capacities of the fixed per-env slots of the batched state (no reference equivalent)
                 traj_cap=None, corr_cap=None, route_cap=128, init_traj_cap=None, n_static=None,
+                # stream of the per-frame uniform draws that replace the global `random` (ENV:1156)
+                rng_seed=0, env_id_base=0,
                 **kwargs):
     """Same signature and defaults as ``Game.__init__`` (ENV:45-105); unknown kwargs are swallowed like the
     reference's ``**kwargs`` (ENV:104)."""
@@ -130,13 +132,10 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
         raise NotImplementedError("manual_control (pygame event loop, ENV:913-915) is not part of the batched step path")
     if random_frames_per_step is not None:
         raise NotImplementedError("random_frames_per_step draws np.random inside step (ENV:939-940); not supported yet")
-    if type(leader_speed_regime) in (dict, OrderedDict) or type(leader_acceleration_regime) in (dict, OrderedDict):
-        raise NotImplementedError("leader_speed_regime / leader_acceleration_regime (ENV:1143-1174, global `random` "
-                                  "per frame) are scheduled for a later round (SURVEY.md config E)")
-    if leader_speed_regime is not None:
+    if leader_speed_regime is not None and type(leader_speed_regime) not in (dict, OrderedDict):
         warn("leader_speed_regime должен быть dict или OrderedDict, получено: {}, будет проигнорировано".format(
             type(leader_speed_regime)))  # ENV:387-389
-    if leader_acceleration_regime is not None:
+    if leader_acceleration_regime is not None and type(leader_acceleration_regime) not in (dict, OrderedDict):
         warn("leader_acceleration_regime должен быть dict, получено: {}, будет проигнорировано".format(
             type(leader_acceleration_regime)))
     if simulation_time_limit is not None:
@@ -264,6 +263,27 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
         lc.angle_offset, lc.after_tracker, lc.out_offset = l.angle_offset, int(l.after_tracker), off
         lc.pad_sectors = int(l.pad_sectors)
         off += l.history * l.width
+
+    # ---- leader regimes (ENV:382-397): int(key) -> value in dict insertion order ---------------------------------
+    c.n_speed_regime, c.n_acc_regime = -1, -1
+    if type(leader_speed_regime) in (dict, OrderedDict):
+        if len(leader_speed_regime) > abi.FTL_MAX_REGIME:
+            raise NotImplementedError("at most %d leader_speed_regime entries" % abi.FTL_MAX_REGIME)
+        c.n_speed_regime = len(leader_speed_regime)
+        for i, (k, v) in enumerate(leader_speed_regime.items()):
+            c.speed_key[i] = int(k)
+            if type(v) in (tuple, list):                       # ENV:1155-1156: uniform(v[0], v[1]) every frame
+                c.speed_is_range[i], c.speed_lo[i], c.speed_hi[i] = 1, float(v[0]), float(v[1])
+            else:
+                c.speed_is_range[i], c.speed_lo[i], c.speed_hi[i] = 0, float(v), float(v)
+    if type(leader_acceleration_regime) in (dict, OrderedDict):
+        if len(leader_acceleration_regime) > abi.FTL_MAX_REGIME:
+            raise NotImplementedError("at most %d leader_acceleration_regime entries" % abi.FTL_MAX_REGIME)
+        c.n_acc_regime = len(leader_acceleration_regime)
+        for i, (k, v) in enumerate(leader_acceleration_regime.items()):
+            c.acc_key[i], c.acc_val[i] = int(k), float(v)
+    c.rng_seed = int(rng_seed) & ((1 << 64) - 1)
+    c.env_id_base = int(env_id_base)
 
     # ---- capacities ---------------------------------------------------------------------------------
     # leader_factual_trajectory: initial int(dist/(5*v)) points, dist < 0.9*max_distance, then one point per

@@ -55,6 +55,7 @@ int validate(const ftl_config& c, std::string& why) {
         REQ(c.tracker_saving_period > 0, "tracker saving_period must be positive");
         REQ(c.corridor_length > 0 && c.corridor_width > 0, "corridor_length / corridor_width must be positive");
     }
+    REQ(c.n_speed_regime <= FTL_MAX_REGIME && c.n_acc_regime <= FTL_MAX_REGIME, "too many regime entries");
     for (int k = 0; k < c.n_lasers; k++) {
         const ftl_laser_cfg& l = c.lasers[k];
         REQ(l.count > 0 && l.count <= 1024, "laser %d: bad lasers_count", k);
@@ -100,6 +101,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         P.rays_k[k] = rays; rays += cfg->lasers[k].count;
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
+    P.bb_in_lds = ((size_t)(FTL_WAVE / (P.R <= 4 ? 4 : 8)) * (cfg->traj_cap / FTL_TRAJ_BLOCK) * 16 <= 12 * 1024) ? 1 : 0;
     {   // row width / common history of the fused sensorPrev output
         int w = 0, hcommon = cfg->n_lasers ? cfg->lasers[0].history : 0;
         for (int k = 0; k < cfg->n_lasers; k++) { P.pol_off[k] = w; w += cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1); if (cfg->lasers[k].history != hcommon) hcommon = -1; }
@@ -201,11 +203,11 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
     // frame loop: G lanes per env (4 for <= 2 dynamic obstacles, else 8)
     if (h->P.R <= 4) {
         const int epw = FTL_WAVE / 4;
-        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32 + (size_t)epw * (h->P.cfg.traj_cap / FTL_TRAJ_BLOCK) * 16;
+        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32 + (h->P.bb_in_lds ? (size_t)epw * (h->P.cfg.traj_cap / FTL_TRAJ_BLOCK) * 16 : 0);
         hipLaunchKernelGGL(ftl_frames_group_kernel<4>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
     } else {
         const int epw = FTL_WAVE / 8;
-        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32 + (size_t)epw * (h->P.cfg.traj_cap / FTL_TRAJ_BLOCK) * 16;
+        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32 + (h->P.bb_in_lds ? (size_t)epw * (h->P.cfg.traj_cap / FTL_TRAJ_BLOCK) * 16 : 0);
         hipLaunchKernelGGL(ftl_frames_group_kernel<8>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
     }
     if (h->P.cfg.n_lasers > 0) {

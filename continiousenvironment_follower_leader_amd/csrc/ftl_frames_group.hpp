@@ -54,14 +54,24 @@ template <int G> __device__ __forceinline__ void group_argmin(float& v, int& idx
     }
 }
 
+// device twin of ftl_mix64 / ftl_uniform01 (include/ftl.h): the stream that replaces random.uniform at ENV:1156
+__device__ __forceinline__ unsigned long long d_mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31; return x;
+}
+__device__ __forceinline__ double d_uniform01(unsigned long long seed, unsigned long long env_id, unsigned long long resets, unsigned long long frame) {
+    unsigned long long key = d_mix64(seed + 0x9E3779B97F4A7C15ULL * (env_id + 1)) ^ d_mix64(0xD1B54A32D192ED03ULL * (resets + 1));
+    return (double)(d_mix64(key + 0x9E3779B97F4A7C15ULL * (frame + 1)) >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // per-lane context: robot r of env `env`, env scalars replicated over the group
 struct GCtx {
     int env, r, slot;
     bool valid;          // env < n_envs
     int scen, cur_target_id, leader_finished, done, crash, is_in_box, is_on_trace, too_close;
     int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
-    int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint, green_tiny;
+    int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint, green_tiny, resets, acc_consumed;
     double acc_penalty, overall_reward, cur_tx, cur_ty;
+    double cur_mult, cur_acc, cum_speed;   // leader regimes (ENV:412, 449, 591-592, 1143-1174)
     double green_w;      // running length of the green-zone window (approximate; decisions near the threshold are re-derived exactly)
     Robot rb;
 };
@@ -77,6 +87,8 @@ __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
     E.corr_hi = ei[FTL_EI_CORR_HI]; E.seed_end = ei[FTL_EI_SEED_END]; E.snap_count = ei[FTL_EI_SNAP_COUNT];
     E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
     E.snap_head = ei[FTL_EI_SNAP_HEAD]; E.hint = ei[FTL_EI_HINT]; E.green_tiny = ei[FTL_EI_GREEN_TINY];
+    E.resets = ei[FTL_EI_RESETS]; E.acc_consumed = ei[FTL_EI_ACC_CONSUMED];
+    E.cur_mult = ed[FTL_ED_CUR_MULT]; E.cur_acc = ed[FTL_ED_CUR_ACC]; E.cum_speed = ed[FTL_ED_CUM_SPEED];
     E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
     E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1]; E.green_w = ed[FTL_ED_GREEN_W];
     int rr = (E.r < P.R) ? E.r : 0;          // idle lanes mirror robot 0 (never committed)
@@ -107,8 +119,10 @@ __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
         ei[FTL_EI_CORR_HI] = E.corr_hi; ei[FTL_EI_SEED_END] = E.seed_end; ei[FTL_EI_SNAP_COUNT] = E.snap_count;
         ei[FTL_EI_ERROR] = E.error; ei[FTL_EI_EPISODES] = E.episodes; ei[FTL_EI_GREEN_COUNT] = E.green_count; ei[FTL_EI_GREEN_LEN] = E.green_len;
         ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SNAP_HEAD] = E.snap_head; ei[FTL_EI_HINT] = E.hint; ei[FTL_EI_GREEN_TINY] = E.green_tiny; ei[FTL_EI_PAD] = 0;
+        ei[FTL_EI_RESETS] = E.resets; ei[FTL_EI_ACC_CONSUMED] = E.acc_consumed;
+        ed[FTL_ED_CUR_MULT] = E.cur_mult; ed[FTL_ED_CUR_ACC] = E.cur_acc; ed[FTL_ED_CUM_SPEED] = E.cum_speed;
         ed[FTL_ED_ACC_PENALTY] = E.acc_penalty; ed[FTL_ED_OVERALL_REWARD] = E.overall_reward;
-        ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty; ed[FTL_ED_GREEN_W] = E.green_w; ed[FTL_ED_PAD] = 0.0;
+        ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty; ed[FTL_ED_GREEN_W] = E.green_w;
     }
     if (E.r < P.R) {
         size_t ro = (size_t)E.env * P.R + E.r;
@@ -161,6 +175,7 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         E.green_count = 0; E.green_len = -1; E.green_w = 0.0; E.green_tiny = 0; E.error = 0; E.scan_ok = 0;
         E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0; E.snap_head = 0;
         E.hint = 0;
+        E.cur_mult = 1.0; E.cur_acc = 0.0; E.cum_speed = 0.0; E.resets += 1;      // ENV:449, 591-592; acc_consumed persists (ENV:1170)
     }
     // group-uniform from here on (go is the same in every lane of a group), so the broadcasts are safe
     float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py);
@@ -376,8 +391,31 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         tx = (double)lpx0 + co * lvl; ty = (double)lpy0 + s * lvl;
         E.rb.tgt_x = tx; E.rb.tgt_y = ty;
     }
+    // leader speed / acceleration regimes (ENV:1048-1058, 1143-1174); evaluated only while the leader is under way
+    double lspeed = c.leader.max_speed + 0;
+    if (!E.leader_finished && (c.n_speed_regime >= 0 || c.n_acc_regime >= 0)) {
+        double speed = c.leader.max_speed, acceleration = 0;
+        if (c.n_speed_regime >= 0) {
+            int sel = -1;
+            for (int i = 0; i < c.n_speed_regime; i++) if (c.speed_key[i] <= E.step_count) sel = i;   // dict order, last match wins
+            if (sel >= 0) {
+                if (c.speed_is_range[sel]) {
+                    double u = d_uniform01(c.rng_seed, (unsigned long long)(c.env_id_base + E.env), (unsigned long long)E.resets, (unsigned long long)E.step_count);
+                    E.cur_mult = c.speed_lo[sel] + (c.speed_hi[sel] - c.speed_lo[sel]) * u;
+                } else E.cur_mult = c.speed_lo[sel];
+            }
+            speed = c.leader.max_speed * E.cur_mult;
+        }
+        if (c.n_acc_regime >= 0) {
+            for (int i = 0; i < c.n_acc_regime; i++)
+                if (!((E.acc_consumed >> i) & 1) && c.acc_key[i] <= E.step_count) { E.cur_acc = c.acc_val[i]; E.cum_speed = E.cur_acc; E.acc_consumed |= 1 << i; }
+            E.cum_speed += E.cur_acc;
+            acceleration = (E.cum_speed * c.leader.max_speed) / c.frames_per_step;
+        }
+        lspeed = speed + acceleration;
+    }
     bool steers = (act && r == 0 && !E.leader_finished) || is_bear;
-    if (steers) steer_to_point(E.rb, L, tx, ty, r == 0, L.max_speed + 0);
+    if (steers) steer_to_point(E.rb, L, tx, ty, r == 0, lspeed);
     if (E.leader_finished) {                                   // ENV:1062-1065
         if (r == 0) { command_forward(E.rb, L, 0); command_turn(E.rb, L, 0, 0); }
         i2 = FTL_LEADER_FINISHED;
@@ -532,7 +570,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                 float4* bb = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK) + E.traj_len / FTL_TRAJ_BLOCK;
                 float4 box = (E.traj_len % FTL_TRAJ_BLOCK == 0) ? make_float4(lpx, lpy, lpx, lpy) : *bb;
                 box.x = fminf(box.x, lpx); box.y = fminf(box.y, lpy); box.z = fmaxf(box.z, lpx); box.w = fmaxf(box.w, lpy);
-                *bb = box; s_bb[E.traj_len / FTL_TRAJ_BLOCK] = box;
+                *bb = box; if (P.bb_in_lds) s_bb[E.traj_len / FTL_TRAJ_BLOCK] = box;
             }
             E.traj_len += 1;
         } else E.error |= FTL_ERR_TRAJ_OVERFLOW;
@@ -806,9 +844,12 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         double reward = 0; int i0 = 0, i1 = 0, i2 = 0;
         const int4* near = s_near + (size_t)E.slot * P.cfg.n_static;
         const int nblk = P.cfg.traj_cap / FTL_TRAJ_BLOCK;
-        float4* bbl = s_bb + (size_t)E.slot * nblk;               // this env's block bounding boxes for the step
-        {
-            const float4* bbg = reinterpret_cast<const float4*>(P.traj_bb) + (size_t)E.env * nblk;
+        // this env's block bounding boxes: staged in LDS for the step when they fit (long-horizon configs read them
+        // from global memory instead -- the LDS copy is an optimisation, not a requirement)
+        float4* bbg = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * nblk;
+        float4* bbl = bbg;
+        if (P.bb_in_lds) {
+            bbl = s_bb + (size_t)E.slot * nblk;
             for (int b = E.r; b * FTL_TRAJ_BLOCK < E.traj_len; b += G) bbl[b] = bbg[b];
         }
         __syncthreads();

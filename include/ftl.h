@@ -32,6 +32,7 @@ extern "C" {
 #define FTL_ABI_VERSION 1
 #define FTL_MAX_BEARS 4   /* bears with index >= 4 draw from `random` inside step (ENV:750-754): unsupported */
 #define FTL_MAX_LASERS 4
+#define FTL_MAX_REGIME 16 /* entries of leader_speed_regime / leader_acceleration_regime */
 #define FTL_OBS_NUM 10    /* numerical_features, ENV:1793-1802 */
 #define FTL_TRAJ_BLOCK 32 /* trajectory points per bounding-box block (state field "traj_bb"; traj_cap is a multiple) */
 
@@ -109,7 +110,30 @@ typedef struct ftl_config {
     double crash_penalty, too_close_penalty, leader_movement_reward;
     ftl_robot_params leader, follower, bear;
     ftl_laser_cfg lasers[FTL_MAX_LASERS];
+    /* leader_speed_regime (ENV:382-386, 1143-1157): entries in dict insertion order; the LAST entry with key <=
+     * step_count (frames) wins; a [lo, hi] entry draws uniform(lo, hi) EVERY frame.  n_speed_regime < 0: None. */
+    int32_t n_speed_regime;
+    int32_t n_acc_regime;                /* leader_acceleration_regime (ENV:390-394, 1159-1174); < 0: None */
+    int32_t speed_key[FTL_MAX_REGIME];
+    int32_t speed_is_range[FTL_MAX_REGIME];
+    int32_t acc_key[FTL_MAX_REGIME];
+    int32_t env_id_base;                 /* global index of env 0 of this handle (multi-GPU shards draw distinct streams) */
+    int32_t _pad1;
+    double speed_lo[FTL_MAX_REGIME], speed_hi[FTL_MAX_REGIME];
+    double acc_val[FTL_MAX_REGIME];
+    uint64_t rng_seed;                   /* seed of the counter-based streams that replace the global `random` (ftl_uniform01) */
 } ftl_config;
+
+/* Counter-based uniform stream that stands in for `random.uniform` at ENV:1156: the draw of
+ * frame `frame` of the `resets`-th episode of global env `env_id` is a pure function of (rng_seed, env_id, resets,
+ * frame), so the oracle, the device and the golden generator agree without sharing generator state. */
+static inline uint64_t ftl_mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31; return x;
+}
+static inline double ftl_uniform01(uint64_t rng_seed, uint64_t env_id, uint64_t resets, uint64_t frame) {
+    uint64_t key = ftl_mix64(rng_seed + 0x9E3779B97F4A7C15ULL * (env_id + 1)) ^ ftl_mix64(0xD1B54A32D192ED03ULL * (resets + 1));
+    return (double)(ftl_mix64(key + 0x9E3779B97F4A7C15ULL * (frame + 1)) >> 11) * (1.0 / 9007199254740992.0);
+}
 
 /* Scenario pool = output of the reference's reset() (ENV:434-543) for P episodes, device arrays.
  * Robots are ordered leader, follower, bear0.. (R = 2 + n_bears). */
@@ -187,12 +211,16 @@ enum {
     FTL_EI_SNAP_HEAD, /* ring slot the next snapshot goes to (= snap_count mod max_prev_obs, kept incrementally) */
     FTL_EI_HINT,      /* index of a trajectory point that was close to the follower last frame (search hint only) */
     FTL_EI_GREEN_TINY, /* the green window may hold a segment so short that f64 sums of segment lengths are no longer exact */
+    FTL_EI_RESETS,     /* number of resets of this env slot so far (keys the RNG stream of the episode) */
+    FTL_EI_ACC_CONSUMED, /* bit i: entry i of leader_acceleration_regime was consumed -- the reference deletes the key for good (ENV:1170) */
     FTL_EI_PAD, FTL_EI_COUNT
 };
 /* indices into the "env_dbl" state field; bear waypoints follow at FTL_ED_BEAR_POINTS + 2*b */
 enum { FTL_ED_ACC_PENALTY = 0, FTL_ED_OVERALL_REWARD, FTL_ED_SPARE0, FTL_ED_SPARE1, FTL_ED_BEAR_POINTS,
        FTL_ED_GREEN_W = FTL_ED_BEAR_POINTS + 2 * FTL_MAX_BEARS, /* running length of the green-zone window (search acceleration) */
-       FTL_ED_PAD, FTL_ED_COUNT };
+       FTL_ED_CUR_MULT,  /* cur_speed_multiplier (ENV:412, 449, 1150-1156) */
+       FTL_ED_CUR_ACC, FTL_ED_CUM_SPEED, /* cur_leader_acceleration, cur_leader_cumulative_speed (ENV:591-592, 1167-1172) */
+       FTL_ED_COUNT };
 /* per robot: rb_dbl[5] and rb_int[8] */
 enum { FTL_RD_DIRECTION = 0, FTL_RD_SPEED, FTL_RD_ROT_SPEED, FTL_RD_DES_SPEED, FTL_RD_DES_ROT_SPEED, FTL_RD_COUNT };
 enum { FTL_RI_X = 0, FTL_RI_Y, FTL_RI_W, FTL_RI_H, FTL_RI_ROT_DIR, FTL_RI_DES_ROT_DIR, FTL_RI_SPARE0, FTL_RI_SPARE1, FTL_RI_COUNT };

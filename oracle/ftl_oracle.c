@@ -73,6 +73,10 @@ typedef struct ftlo_env {
     snapshot_t* snaps[FTL_MAX_LASERS];
     uint32_t error;
     int lasers_len;
+    /* leader regimes (ENV:412, 449, 591-592, 1143-1174) */
+    double cur_mult, cur_acc, cum_speed;
+    uint32_t acc_consumed;      /* keys the reference deleted from leader_acceleration_regime (never restored) */
+    uint64_t resets;            /* resets of this Game object so far: keys the uniform stream of the episode */
 } ftlo_env;
 
 /* ------------------------------------------------------------------ helpers */
@@ -335,6 +339,32 @@ static double reward_computation(const ftlo_env* e) {
     return res;
 }
 
+/* ENV:1143-1157.  `random.uniform(lo, hi)` = lo + (hi-lo)*random() is drawn from the counter-based stream of
+ * include/ftl.h (the golden generator patches random.uniform with the same function). */
+static double process_leader_speed_regime(ftlo_env* e) {
+    const ftl_config* c = &e->cfg;
+    int sel = -1;
+    for (int i = 0; i < c->n_speed_regime; i++) if (c->speed_key[i] <= e->step_count) sel = i;   /* dict order, last match wins */
+    if (sel >= 0) {
+        if (c->speed_is_range[sel]) {
+            double u = ftl_uniform01(c->rng_seed, (uint64_t)c->env_id_base, e->resets, (uint64_t)e->step_count);
+            e->cur_mult = c->speed_lo[sel] + (c->speed_hi[sel] - c->speed_lo[sel]) * u;
+        } else e->cur_mult = c->speed_lo[sel];
+    }
+    return e->rb[0].p->max_speed * e->cur_mult;
+}
+/* ENV:1159-1174 */
+static double process_leader_acceleration_regime(ftlo_env* e) {
+    const ftl_config* c = &e->cfg;
+    for (int i = 0; i < c->n_acc_regime; i++)
+        if (!((e->acc_consumed >> i) & 1u) && c->acc_key[i] <= e->step_count) {
+            e->cur_acc = c->acc_val[i]; e->cum_speed = e->cur_acc;
+            e->acc_consumed |= 1u << i;                      /* del self.leader_acceleration_regime[cur_key] */
+        }
+    e->cum_speed += e->cur_acc;
+    return e->cum_speed * e->rb[0].p->max_speed;
+}
+
 /* ENV:947-1141; returns the frame reward, writes info */
 static double frame_step(ftlo_env* e, uint8_t info[3]) {
     const ftl_config* c = &e->cfg;
@@ -363,7 +393,9 @@ static double frame_step(ftlo_env* e, uint8_t info[3]) {
         move_to_the_point(&e->rb[2 + b], tx, ty, 0, 0.0);
     }
     if (!e->leader_finished) {                                         /* ENV:1048-1058 */
-        move_to_the_point(leader, e->cur_target[0], e->cur_target[1], 1, leader->p->max_speed + 0);
+        double speed = (c->n_speed_regime >= 0) ? process_leader_speed_regime(e) : leader->p->max_speed;
+        double acceleration = (c->n_acc_regime >= 0) ? process_leader_acceleration_regime(e) / c->frames_per_step : 0;
+        move_to_the_point(leader, e->cur_target[0], e->cur_target[1], 1, speed + acceleration);
     } else {                                                           /* ENV:1062-1065 */
         command_forward(leader, 0); command_turn(leader, 0, 0); info[2] = FTL_LEADER_FINISHED;
     }
@@ -694,6 +726,8 @@ int ftlo_reset(ftlo_env* e, const int32_t* static_rects, const float* robot_pos,
     e->done = 0; e->crash = 0; e->is_in_box = 0; e->is_on_trace = 0; e->too_close = 0; /* ENV:500-503 */
     e->cur_target_id = 1; e->leader_finished = 0; e->finish_timer = -1;          /* ENV:506-514, 542 */
     e->green_count = 0; e->error = 0;
+    e->cur_mult = 1; e->cur_acc = 0; e->cum_speed = 0;                               /* ENV:449, 591-592 */
+    e->resets += 1;
     if (route_len == 0) { e->done = 1; e->cur_target[0] = (double)e->rb[0].px; e->cur_target[1] = (double)e->rb[0].py; }
     else if (route_len > 1) { e->cur_target[0] = route[2]; e->cur_target[1] = route[3]; }
     else return FTL_E_INVALID; /* reference: IndexError at ENV:513 */
@@ -741,6 +775,7 @@ void ftlo_get_counters(const ftlo_env* e, int64_t* c, double* acc) {
     for (int b = 0; b < FTL_MAX_BEARS; b++) c[15 + b] = e->dyn_index[b];
     acc[0] = e->accumulated_penalty; acc[1] = e->overall_reward;
 }
+void ftlo_set_env_id(ftlo_env* e, int env_id) { e->cfg.env_id_base = env_id; }
 int ftlo_get_tracker(const ftlo_env* e, double* hist, double* corr, uint8_t* isf64) {
     memcpy(hist, e->hist, sizeof(double) * 2 * (size_t)e->hist_len);
     memcpy(corr, e->corr, sizeof(double) * 4 * (size_t)e->corr_len);

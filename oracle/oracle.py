@@ -37,6 +37,7 @@ def load_oracle():
         lib.ftlo_get_counters.argtypes = [vp, vp, vp]
         lib.ftlo_get_tracker.argtypes = [vp, vp, vp, vp]
         lib.ftlo_get_traj.argtypes = [vp, vp, C.c_int]
+        lib.ftlo_set_env_id.argtypes = [vp, C.c_int]
         lib.ftlo_step_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         _LIB = lib
     return _LIB
@@ -49,10 +50,12 @@ def _p(a):
 class OracleEnv:
     """One env of the oracle.  ``cfg`` is a ``config.GameConfig``."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, env_id=None):
         self.lib = load_oracle()
         self.cfg = cfg
         self.h = self.lib.ftlo_create(C.byref(cfg.c))
+        if env_id is not None:           # global env index: selects the RNG stream (ftl_uniform01)
+            self.lib.ftlo_set_env_id(self.h, int(env_id))
         self.R = cfg.n_robots
         self.L = cfg.lasers_len
         self.obs_num = np.zeros(abi.FTL_OBS_NUM, np.float32)

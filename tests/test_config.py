@@ -59,7 +59,6 @@ def test_sensor_registry_and_dict_order():
     (dict(follower_sensors={"mystery": {}}), ValueError),                            # CLS:249
     (dict(follower_sensors={"LaserSensor": {}}), NotImplementedError),               # outside the accelerated path
     (dict(manual_control=True), NotImplementedError),
-    (dict(leader_speed_regime={0: 1}), NotImplementedError),
     (dict(bear_number=5), NotImplementedError),
 ])
 def test_constructor_errors(kw, exc):

@@ -41,17 +41,21 @@ def test_hip_matches_reference_episode(name):
     env.reset(torch.zeros(n, dtype=torch.int32))
     torch.cuda.synchronize()
     lnames = meta["laser_names"]
+    # a random speed regime draws from the per-env counter stream (env id in the key): only env 0 replays the episode
+    rnd = any(cfg.c.speed_is_range[i] for i in range(max(cfg.c.n_speed_regime, 0)))
+    envs = [0] if rnd else list(range(n))
+    last = envs[-1]
 
     def check(tag, t):
         num = env.obs_num.cpu().numpy()
         ref = z[tag + ":num"] if t is None else z[tag + ":num"][t]
-        for e in range(n):
+        for e in envs:
             assert close(num[e], ref).all(), (name, t, e, "num", num[e] - ref)
         for ln in lnames:
             got = env.laser_view(ln).cpu().numpy()
             ref = z[tag + ":laser:" + ln] if t is None else z[tag + ":laser:" + ln][t]
             assert got.shape[1:] == ref.shape
-            for e in range(n):
+            for e in envs:
                 assert close(got[e], ref).all(), (name, t, e, ln, np.abs(got[e] - ref).max())
         reft = z[tag + ":target"] if t is None else z[tag + ":target"][t]
         assert np.array_equal(env.target.cpu().numpy()[0], reft), (name, t, "target")
@@ -63,16 +67,16 @@ def test_hip_matches_reference_episode(name):
         env.step(a)
         check("obs", t)
         rew = env.reward.cpu().numpy(); done = env.done.cpu().numpy(); st = env.status.cpu().numpy()
-        for e in range(n):
+        for e in envs:
             assert abs(rew[e] - z["reward"][t]) <= 1e-5, (name, t, rew[e], z["reward"][t])
             assert bool(done[e]) == bool(z["done"][t]), (name, t, "done")
             assert tuple(st[e]) == tuple(z["info"][t]), (name, t, st[e], z["info"][t])
         # internal state against the reference's own objects
-        pos, dbl, ints = _robots(env, n - 1)
+        pos, dbl, ints = _robots(env, last)
         assert np.array_equal(ints[:, :6], z["dbg:robot_i32"][t]), (name, t, "hitboxes / rotation dirs", ints[:, :6], z["dbg:robot_i32"][t])
         assert close(pos, z["dbg:robot_pos"][t]).all(), (name, t, "positions")
         assert np.allclose(dbl, z["dbg:robot_f64"][t], rtol=0, atol=1e-9), (name, t, "controller state")
-        ei = env.state_field("env_int")[n - 1].cpu().numpy()
+        ei = env.state_field("env_int")[last].cpu().numpy()
         cnt = z["dbg:counters"][t]
         got = [ei[abi.EI_STEP_COUNT], ei[abi.EI_TRAJ_LEN], ei[abi.EI_GREEN_COUNT], ei[abi.EI_TARGET_ID], ei[abi.EI_LEADER_FINISHED],
                ei[abi.EI_IN_BOX], ei[abi.EI_ON_TRACE], ei[abi.EI_TOO_CLOSE], ei[abi.EI_CRASH], ei[abi.EI_DONE], ei[abi.EI_FINISH_TIMER]]
@@ -81,7 +85,7 @@ def test_hip_matches_reference_episode(name):
         if "dbg:trk" in z:
             tr = z["dbg:trk"][t]
             assert int(tr[0]) == ei[abi.EI_TRK_COUNTER] and int(tr[1]) == ei[abi.EI_CORR_HI] - ei[abi.EI_CORR_LO], (name, t, tr, ei)
-            hist, corr = env.tracker_obs(n - 1)
+            hist, corr = env.tracker_obs(last)
             assert np.allclose(hist, z["dbg:hist"][t][:int(tr[1])], rtol=0, atol=1e-9), (name, t, "tracker history")
             assert np.allclose(corr.reshape(-1, 4), z["dbg:corr"][t][:int(tr[2])], rtol=0, atol=1e-9), (name, t, "corridor")
         if "dbg:dyn_index" in z:
@@ -145,4 +149,48 @@ def test_hip_matches_oracle_batch(n_envs, steps, policy):
             assert np.array_equal(ri[e][:, :6], dbg["robot_i32"]), (t, e, "hitboxes")
     # float32 observations are expected to be bit-identical except for rare last-ulp trig differences
     assert nmis <= 4, nmis
+    env.close()
+
+
+def test_hip_matches_oracle_regimes():
+    """Config E (leader speed / acceleration regimes, ENV:1143-1174) on a batch with distinct env ids: the random
+    multiplier stream is the counter-based ftl_uniform01(rng_seed, env_id, resets, frame) on both sides; a second
+    reset checks the `resets` key and that consumed acceleration entries persist (ENV:1170)."""
+    from oracle import OracleEnv
+    from golden_util import config_for, load_episode, scenario_arrays
+    eps = [load_episode(n) for n in episode_names() if n.startswith("E_")]
+    assert eps
+    scen = [scenario_arrays(z) for z, _ in eps]
+    cfg = config_for(eps[0][1], scen_route_len=max(len(s["route"]) for s in scen), rng_seed=5, env_id_base=1000)
+    assert cfg.c.n_speed_regime > 0 and cfg.c.n_acc_regime > 0
+    n_envs = 96
+    env = _vec(cfg, n_envs, scen)
+    idx = torch.arange(n_envs, dtype=torch.int32) % len(scen)
+    oras = [OracleEnv(cfg, env_id=1000 + e) for e in range(n_envs)]
+    rng = np.random.default_rng(11)
+    ms, mr = cfg.c.follower.max_speed, cfg.c.follower.max_rotation_speed
+    for rep in range(2):
+        env.reset(idx)
+        for e, o in enumerate(oras):
+            ob = o.reset(**scen[e % len(scen)])
+            assert close(env.obs_num[e].cpu().numpy(), ob["num"]).all()
+        for t in range(130):
+            a = np.stack([rng.uniform(0.6, 1.0, n_envs) * ms, np.clip(rng.normal(0, 0.15 * mr, n_envs), -mr, mr)], 1)
+            env.step(torch.tensor(a, dtype=torch.float64, device="cuda:0"))
+            num = env.obs_num.cpu().numpy(); las = env.lasers.cpu().numpy(); rew = env.reward.cpu().numpy()
+            done = env.done.cpu().numpy(); st = env.status.cpu().numpy()
+            rf = env.state_field("rb_pos").cpu().numpy().reshape(n_envs, cfg.n_robots, 2)
+            for e, o in enumerate(oras):
+                ob, r, d, s = o.step(a[e])
+                assert bool(done[e]) == d and tuple(st[e]) == tuple(s), (rep, t, e, "flags")
+                assert abs(rew[e] - r) <= 1e-5
+                assert close(num[e], ob["num"]).all(), (rep, t, e, num[e] - ob["num"])
+                for l in cfg.lasers:
+                    got = las[e, l.out_offset:l.out_offset + l.history * l.count].reshape(l.history, l.count)
+                    assert close(got, ob[l.name]).all(), (rep, t, e, l.name)
+                # leader position bit-exact: the regime multiplier and acceleration feed straight into it
+                assert np.array_equal(rf[e][0], o.debug()["robot_pos"][0]), (rep, t, e, "leader position")
+    # different env ids must have drawn different multipliers (the stream is per env, not shared)
+    lead = env.state_field("rb_pos").cpu().numpy().reshape(n_envs, cfg.n_robots, 2)[:, 0]
+    assert len({tuple(p) for p in lead[0::len(scen)]}) > 1
     env.close()
