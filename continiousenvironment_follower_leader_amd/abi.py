@@ -24,8 +24,8 @@ FTL_STEP_AUTO_RESET = 1
 (EI_SCEN, EI_TARGET_ID, EI_LEADER_FINISHED, EI_DONE, EI_CRASH, EI_IN_BOX, EI_ON_TRACE, EI_TOO_CLOSE,
  EI_STEP_COUNT, EI_FINISH_TIMER, EI_TRAJ_LEN, EI_TRK_COUNTER, EI_CORR_LO, EI_CORR_HI, EI_SEED_END,
  EI_SNAP_COUNT, EI_DYN_INDEX0, EI_DYN_INDEX1, EI_DYN_INDEX2, EI_DYN_INDEX3, EI_ERROR, EI_EPISODES,
- EI_GREEN_COUNT, EI_GREEN_LEN, EI_SCAN_OK, EI_SNAP_HEAD, EI_HINT, EI_GREEN_TINY, EI_RESETS, EI_ACC_CONSUMED, EI_PAD,
- EI_COUNT) = range(32)
+ EI_GREEN_COUNT, EI_GREEN_LEN, EI_SCAN_OK, EI_SNAP_HEAD, EI_HINT, EI_GREEN_TINY, EI_RESETS, EI_ACC_CONSUMED,
+ EI_HINT_X, EI_HINT_Y, EI_CLR_GREEN, EI_CLR_ALL, EI_PAD, EI_COUNT) = range(36)
 ED_ACC_PENALTY, ED_OVERALL_REWARD, ED_SPARE0, ED_SPARE1, ED_BEAR_POINTS = range(5)
 ED_GREEN_W = ED_BEAR_POINTS + 2 * FTL_MAX_BEARS
 ED_CUR_MULT, ED_CUR_ACC, ED_CUM_SPEED = ED_GREEN_W + 1, ED_GREEN_W + 2, ED_GREEN_W + 3

@@ -54,6 +54,24 @@ template <int G> __device__ __forceinline__ void group_argmin(float& v, int& idx
     }
 }
 
+#ifdef FTL_PROFILE_PATHS
+// diagnostic build only (profiles/tools/path_counts.py): how often each branch of the frame is taken
+__device__ unsigned long long g_prof[16];
+#ifdef FTL_PROFILE_NOCOUNT      // cycle sections only: the contended counting atomics would distort them
+#define FTL_PROF(slot, cond, n) do { } while (0)
+#else
+#define FTL_PROF(slot, cond, n) do { if (cond) atomicAdd(&g_prof[slot], (unsigned long long)(n)); } while (0)
+#endif
+__device__ unsigned long long g_cyc[16];
+__shared__ unsigned long long s_cyc[16];           // per-wave accumulators, flushed once at the end of the kernel
+#define FTL_TIC(slot) do { unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) s_cyc[slot] += _t - _tprev; _tprev = _t; } while (0)
+#define FTL_TIC_INIT unsigned long long _tprev = __builtin_readcyclecounter()
+#else
+#define FTL_PROF(slot, cond, n) do { } while (0)
+#define FTL_TIC(slot) do { } while (0)
+#define FTL_TIC_INIT do { } while (0)
+#endif
+
 // device twin of ftl_mix64 / ftl_uniform01 (include/ftl.h): the stream that replaces random.uniform at ENV:1156
 __device__ __forceinline__ unsigned long long d_mix64(unsigned long long x) {
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31; return x;
@@ -72,6 +90,8 @@ struct GCtx {
     int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint, green_tiny, resets, acc_consumed;
     double acc_penalty, overall_reward, cur_tx, cur_ty;
     double cur_mult, cur_acc, cum_speed;   // leader regimes (ENV:412, 449, 591-592, 1143-1174)
+    float hx, hy;        // coordinates of trajectory point `hint`
+    float clr_g, clr_a;  // lower bounds: distance follower -> any green point / any trajectory point (see g_frame)
     double green_w;      // running length of the green-zone window (approximate; decisions near the threshold are re-derived exactly)
     Robot rb;
 };
@@ -88,6 +108,8 @@ __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
     E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
     E.snap_head = ei[FTL_EI_SNAP_HEAD]; E.hint = ei[FTL_EI_HINT]; E.green_tiny = ei[FTL_EI_GREEN_TINY];
     E.resets = ei[FTL_EI_RESETS]; E.acc_consumed = ei[FTL_EI_ACC_CONSUMED];
+    E.hx = __int_as_float(ei[FTL_EI_HINT_X]); E.hy = __int_as_float(ei[FTL_EI_HINT_Y]);
+    E.clr_g = __int_as_float(ei[FTL_EI_CLR_GREEN]); E.clr_a = __int_as_float(ei[FTL_EI_CLR_ALL]);
     E.cur_mult = ed[FTL_ED_CUR_MULT]; E.cur_acc = ed[FTL_ED_CUR_ACC]; E.cum_speed = ed[FTL_ED_CUM_SPEED];
     E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
     E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1]; E.green_w = ed[FTL_ED_GREEN_W];
@@ -120,6 +142,8 @@ __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
         ei[FTL_EI_ERROR] = E.error; ei[FTL_EI_EPISODES] = E.episodes; ei[FTL_EI_GREEN_COUNT] = E.green_count; ei[FTL_EI_GREEN_LEN] = E.green_len;
         ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SNAP_HEAD] = E.snap_head; ei[FTL_EI_HINT] = E.hint; ei[FTL_EI_GREEN_TINY] = E.green_tiny; ei[FTL_EI_PAD] = 0;
         ei[FTL_EI_RESETS] = E.resets; ei[FTL_EI_ACC_CONSUMED] = E.acc_consumed;
+        ei[FTL_EI_HINT_X] = __float_as_int(E.hx); ei[FTL_EI_HINT_Y] = __float_as_int(E.hy);
+        ei[FTL_EI_CLR_GREEN] = __float_as_int(E.clr_g); ei[FTL_EI_CLR_ALL] = __float_as_int(E.clr_a);
         ed[FTL_ED_CUR_MULT] = E.cur_mult; ed[FTL_ED_CUR_ACC] = E.cur_acc; ed[FTL_ED_CUM_SPEED] = E.cum_speed;
         ed[FTL_ED_ACC_PENALTY] = E.acc_penalty; ed[FTL_ED_OVERALL_REWARD] = E.overall_reward;
         ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty; ed[FTL_ED_GREEN_W] = E.green_w;
@@ -174,7 +198,7 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         E.cur_target_id = 1; E.leader_finished = 0; E.finish_timer = -1;
         E.green_count = 0; E.green_len = -1; E.green_w = 0.0; E.green_tiny = 0; E.error = 0; E.scan_ok = 0;
         E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0; E.snap_head = 0;
-        E.hint = 0;
+        E.hint = 0; E.hx = 3.0e38f; E.hy = 3.0e38f; E.clr_g = 0.0f; E.clr_a = 0.0f;     // no cached point, no bound
         E.cur_mult = 1.0; E.cur_acc = 0.0; E.cum_speed = 0.0; E.resets += 1;      // ENV:449, 591-592; acc_consumed persists (ENV:1170)
     }
     // group-uniform from here on (go is the same in every lane of a group), so the broadcasts are safe
@@ -298,12 +322,13 @@ __device__ __forceinline__ int g_closest(const float2* tr, int r, float px, floa
 // `reversed`: the reference enumerates the range from hi-1 down to lo (the green list), ties go to the HIGHER index.
 template <int G>
 __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* bb, int r, float px, float py, int lo, int hi,
-                                               float thr2, bool reversed, int init, float init_d2, float& best, int& bi) {
-    best = __int_as_float(0x7f800000); bi = 0x7fffffff;
+                                               float thr2, bool reversed, int init, float init_d2, float2 init_p, float& best, int& bi, float2& bp, float& skipmin) {
+    best = __int_as_float(0x7f800000); bi = 0x7fffffff; bp = init_p;     // the arg-min's coordinates travel with it: no re-load
     int key = 0x7fffffff;                                     // enumeration order of the reference (smaller = earlier)
+    skipmin = __int_as_float(0x7f800000);                     // smallest box distance^2 among the blocks NOT scanned
     float bound = thr2;                                       // blocks farther than this cannot hold the wanted arg-min
     if (init >= lo && init < hi) {                            // a member of the range whose distance is already known
-        if (r == 0) { best = init_d2; bi = init; key = reversed ? (hi - 1 - init) : init; }   // (from the hint window):
+        if (r == 0) { best = init_d2; bi = init; key = reversed ? (hi - 1 - init) : init; }   // (from the hint window, with init_p):
         bound = fminf(bound, init_d2);                         // it bounds the minimum
     }
     const int b_lo = lo / FTL_TRAJ_BLOCK, b_hi = (hi - 1) / FTL_TRAJ_BLOCK;
@@ -316,9 +341,12 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
             bd2 = dx * dx + dy * dy - 1e-2f;                  // slack far above the float32 rounding of the box test
         }
         unsigned m = (unsigned)((__ballot(bd2 <= bound) >> (threadIdx.x & ~(G - 1))) & ((1ull << G) - 1ull));
+        if (!(bd2 <= bound)) skipmin = fminf(skipmin, bd2);   // per lane; combined over the group at the end
         while (m) {                                           // group-uniform: every lane of the group sees the same mask
             int k = __ffs(m) - 1; m &= m - 1;
-            if (!(__shfl(bd2, k, G) <= bound)) continue;      // the bound may have tightened since the mask was formed
+            float kd2 = __shfl(bd2, k, G);
+            if (!(kd2 <= bound)) { skipmin = fminf(skipmin, kd2); continue; }   // the bound may have tightened since the mask was formed
+            FTL_PROF(reversed ? 6 : 7, r == 0, 1);
             int s0 = (b0 + k) * FTL_TRAJ_BLOCK;
             int i0 = max(s0, lo), i1 = min(s0 + FTL_TRAJ_BLOCK, hi);
 #pragma unroll 8
@@ -327,7 +355,7 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
                 float ddx = q.x - px, ddy = q.y - py;
                 float d2 = ddx * ddx + ddy * ddy;
                 int ky = reversed ? (hi - 1 - i) : i;
-                if (d2 < best || (d2 == best && ky < key)) { best = d2; bi = i; key = ky; }
+                if (d2 < best || (d2 == best && ky < key)) { best = d2; bi = i; key = ky; bp = q; }
             }
             float gbest = best;                               // tighten the bound with what the group has seen so far
 #pragma unroll
@@ -339,8 +367,10 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) {
         float ov = __shfl_xor(best, off, G); int ok = __shfl_xor(key, off, G); int oi = __shfl_xor(bi, off, G);
+        float ox = __shfl_xor(bp.x, off, G), oy = __shfl_xor(bp.y, off, G);
         bool take = (ov < best) || (ov == best && ok < key);
-        if (take) { best = ov; key = ok; bi = oi; }
+        if (take) { best = ov; key = ok; bi = oi; bp.x = ox; bp.y = oy; }
+        skipmin = fminf(skipmin, __shfl_xor(skipmin, off, G));
     }
 }
 
@@ -350,11 +380,13 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     const ftl_config& c = P.cfg;
     const int r = E.r;
     const bool act = E.valid && r < P.R;
+    FTL_TIC_INIT;
     E.is_in_box = 0; E.is_on_trace = 0;
     i0 = FTL_MISSION_IN_PROGRESS; i1 = FTL_AGENT_MOVING; i2 = FTL_LEADER_MOVING;
 
     // the other robots as the follower's collision test and the bears' way-points see them: before anybody moves
     const float lpx0 = gb_f<G, 0>(E.rb.px), lpy0 = gb_f<G, 0>(E.rb.py);
+    const float fpx0 = gb_f<G, 1>(E.rb.px), fpy0 = gb_f<G, 1>(E.rb.py);
     const double ldir0 = gb_d<G, 0>(E.rb.direction);
     const int orx = E.rb.rx, ory = E.rb.ry, orw = E.rb.rw, orh = E.rb.rh;
 
@@ -441,6 +473,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         bool out = (double)fpx > (double)c.width || (double)fpy > (double)c.height || fpx < 0.0f || fpy < 0.0f;
         if (fhit || out) { E.crash = 1; E.done = 1; i0 = FTL_MISSION_FAIL; i1 = FTL_AGENT_CRASH; }
     }
+    FTL_TIC(0);
     // green zone (ENV:968-969): recomputed when a point was appended
     const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)E.env * c.traj_cap * 2);
 #ifndef FTL_ABLATE_GREEN
@@ -484,24 +517,55 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         if (exact) { int why = (E.green_len != nn - 1) ? 1 : (E.green_count < 1 ? 2 : 3); E.error = (E.error & 0xff) | (why << 8) | ((((E.error >> 16) + 1) & 0xffff) << 16); }
 #endif
 #ifndef FTL_ABLATE_EXACT
+        FTL_PROF(4, E.valid && r == 0 && exact, 1);
         if (exact) Gn = g_green_walk<G>(P, E, W, tiny);
 #endif
         E.green_count = Gn; E.green_w = W; E.green_len = nn; E.green_tiny = tiny;
     }
 #endif
+    FTL_TIC(1);
     const int Gc = E.green_count, n = E.traj_len;
     // _check_agent_position (ENV:1906-1937).  Its two arg-min searches only feed threshold tests: closest green point
     // within epsilon -> on trace + in box; within max_dev -> in box; otherwise closest point of the WHOLE trajectory
     // within epsilon -> on trace.  g_range_argmin() returns the reference's arg-min whenever it matters for such a
     // test; a hint window around the point that was close last frame settles the common on-trace case first.
 #ifndef FTL_ABLATE_AGENT
+    FTL_PROF(0, E.valid && r == 0, 1);
+    // Search caches (exact: they only decide which points have to be looked at).  clr_g / clr_a are lower bounds on the
+    // follower's distance to every green point / every trajectory point: a search leaves behind the smallest distance it
+    // saw or proved (block boxes it skipped), the follower's own displacement is subtracted every frame and an appended
+    // point enters with its distance.  (hx,hy) are the coordinates of point `hint`; one such point clearly inside a
+    // threshold settles "the arg-min is inside it" without touching memory.
+    {
+        float mx = fpx - fpx0, my = fpy - fpy0;
+        float disp = sqrtf(mx * mx + my * my) * 1.000001f + 1e-5f;
+        E.clr_g -= disp; E.clr_a -= disp;
+    }
     if (Gc > 2) {
+        FTL_PROF(1, E.valid && r == 0, 1);
         const double eps = c.leader_pos_epsilon, mdev = c.max_dev;
+        const double far = fmax(mdev, eps);
         const float4* bb = s_bb;                              // block bounding boxes, staged in LDS for the step
         const int g_lo = n - 1 - Gc;                           // green points are indices g_lo .. n-2
+        // "some point is clearly within epsilon" => the arg-min point (smallest float32 squared distance) is too
+        const float eps2_lo = (float)(eps * eps * (1.0 - 1e-5)), dev2_lo = (float)(mdev * mdev * (1.0 - 1e-5));
+        const float eps_hi = (float)(eps * (1.0 + 1e-5)) + 1e-3f, far_hi = (float)(far * (1.0 + 1e-5)) + 1e-3f;
+        const bool h_green = E.hint >= g_lo && E.hint <= n - 2;
+        float hd2;
+        { float dx = E.hx - fpx, dy = E.hy - fpy; hd2 = dx * dx + dy * dy; }
+        int fast = 0;
+        if (h_green && hd2 < eps2_lo) fast = 1;                                         // a green point within epsilon
+        else if (h_green && hd2 < dev2_lo && E.clr_g > eps_hi) fast = 2;                // none within epsilon, one within max_dev
+        else if (E.clr_g > far_hi) fast = (E.clr_a > eps_hi) ? 3 : (hd2 < eps2_lo ? 4 : 0);   // no green point in reach
+        FTL_PROF(2, E.valid && r == 0 && fast != 0, 1);
+        if (fast == 1) { E.is_on_trace = 1; E.is_in_box = 1; }
+        else if (fast == 2) { E.is_in_box = 1; }
+        else if (fast == 4) { E.is_on_trace = 1; }
+        else if (fast == 0) {
         // hint window: 4*G points around the point that was closest last frame, one memory round trip
         float wbest = __int_as_float(0x7f800000); int widx = 0x7fffffff;      // over the whole window
         float gbest = __int_as_float(0x7f800000); int gidx = 0x7fffffff;      // over its green members (ties -> higher index)
+        float2 wp = make_float2(0.0f, 0.0f), gp = wp;                         // their coordinates
         {
             int w0 = E.hint - 2 * G; w0 = w0 < 0 ? 0 : w0;
 #pragma unroll
@@ -511,50 +575,64 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                     float2 p = tr[i];
                     float dx = p.x - fpx, dy = p.y - fpy;
                     float d2 = dx * dx + dy * dy;
-                    if (d2 < wbest) { wbest = d2; widx = i; }
-                    if (i >= g_lo && i <= n - 2 && d2 <= gbest) { gbest = d2; gidx = i; }
+                    if (d2 < wbest) { wbest = d2; widx = i; wp = p; }
+                    if (i >= g_lo && i <= n - 2 && d2 <= gbest) { gbest = d2; gidx = i; gp = p; }
                 }
             }
-            group_argmin<G>(wbest, widx);
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) {
+                float ov = __shfl_xor(wbest, off, G); int oi = __shfl_xor(widx, off, G);
+                float ox = __shfl_xor(wp.x, off, G), oy = __shfl_xor(wp.y, off, G);
+                bool take = (ov < wbest) || (ov == wbest && oi < widx);
+                if (take) { wbest = ov; widx = oi; wp.x = ox; wp.y = oy; }
+            }
 #pragma unroll
             for (int off = G / 2; off >= 1; off >>= 1) {
                 float ov = __shfl_xor(gbest, off, G); int oi = __shfl_xor(gidx, off, G);
+                float ox = __shfl_xor(gp.x, off, G), oy = __shfl_xor(gp.y, off, G);
                 bool take = (ov < gbest) || (ov == gbest && oi != 0x7fffffff && (gidx == 0x7fffffff || oi > gidx));
-                if (take) { gbest = ov; gidx = oi; }
+                if (take) { gbest = ov; gidx = oi; gp.x = ox; gp.y = oy; }
             }
         }
-        // "some point is clearly within epsilon" => the arg-min point (smallest float32 squared distance) is too
-        const float eps2_lo = (float)(eps * eps * (1.0 - 1e-5));
+        FTL_TIC(8);
         if (gbest < eps2_lo) {                                 // a green point is within epsilon
-            E.is_on_trace = 1; E.is_in_box = 1; E.hint = gidx;
+            E.is_on_trace = 1; E.is_in_box = 1; E.hint = gidx; E.hx = gp.x; E.hy = gp.y;
         }
 #ifndef FTL_ABLATE_SEARCH
         else {
-            const double far = fmax(mdev, eps);
-            float gb2; int gi;
-            g_range_argmin<G>(tr, bb, r, fpx, fpy, g_lo, n - 1, (float)(far * far * (1.0 + 1e-5)) + 1e-2f, true, gidx, gbest, gb2, gi);
+            float gb2; int gi; float2 q; float skip;
+            FTL_PROF(3, E.valid && r == 0, 1);
+            FTL_PROF(8, threadIdx.x == 0, 1);
+            g_range_argmin<G>(tr, bb, r, fpx, fpy, g_lo, n - 1, (float)(far * far * (1.0 + 1e-5)) + 1e-2f, true, gidx, gbest, gp, gb2, gi, q, skip);
+            E.clr_g = sqrtf(fmaxf(fminf(gb2, skip), 0.0f)) * 0.999999f - 1e-3f;       // every green point is at least this far
+            FTL_TIC(11);
             bool in_eps = false, in_dev = false;
             if (gi != 0x7fffffff) {
-                float2 q = tr[gi];
                 in_eps = euclid_f32_le(fpx, fpy, q.x, q.y, eps);
                 in_dev = !in_eps && euclid_f32_le(fpx, fpy, q.x, q.y, mdev);
             }
-            if (in_eps) { E.is_on_trace = 1; E.is_in_box = 1; E.hint = gi; }
-            else if (in_dev) { E.is_in_box = 1; E.is_on_trace = 0; E.hint = gi; }
-            else if (wbest < eps2_lo) { E.is_on_trace = 1; E.is_in_box = 0; E.hint = widx; }   // some point is within epsilon
+            FTL_PROF(10, E.valid && r == 0 && in_eps, 1); FTL_PROF(11, E.valid && r == 0 && in_dev, 1);
+            FTL_PROF(12, E.valid && r == 0 && !in_eps && !in_dev && wbest < eps2_lo, 1);
+            if (in_eps) { E.is_on_trace = 1; E.is_in_box = 1; E.hint = gi; E.hx = q.x; E.hy = q.y; }
+            else if (in_dev) { E.is_in_box = 1; E.is_on_trace = 0; E.hint = gi; E.hx = q.x; E.hy = q.y; }
+            else if (wbest < eps2_lo) { E.is_on_trace = 1; E.is_in_box = 0; E.hint = widx; E.hx = wp.x; E.hy = wp.y; }   // some point is within epsilon
             else {                                             // closest point of the whole trajectory (ENV:1924-1930)
-                float ab2; int ai;
-                g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, widx, wbest, ab2, ai);
+                float ab2; int ai; float2 q2; float skip2;
+                FTL_PROF(5, E.valid && r == 0, 1);
+                FTL_PROF(9, (threadIdx.x & (G - 1)) == 0 && __ffsll((long long)__ballot(1)) - 1 == (int)threadIdx.x, 1);
+                g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, widx, wbest, wp, ab2, ai, q2, skip2);
+                E.clr_a = sqrtf(fmaxf(fminf(ab2, skip2), 0.0f)) * 0.999999f - 1e-3f;  // every trajectory point is at least this far
                 if (ai != 0x7fffffff) {
-                    float2 q2 = tr[ai];
                     if (euclid_f32_le(fpx, fpy, q2.x, q2.y, eps)) { E.is_on_trace = 1; E.is_in_box = 0; }
-                    E.hint = ai;
+                    E.hint = ai; E.hx = q2.x; E.hy = q2.y;
                 }
             }
         }
 #endif
+        }
     }
 #endif
+    FTL_TIC(2);
     E.too_close = euclid_f32_le(lpx0, lpy0, fpx, fpy, c.min_distance);
     {   // leader collision (ENV:1068-1072)
         bool out = (double)lpx > (double)c.width || (double)lpy > (double)c.height || lpx < 0.0f || lpy < 0.0f;
@@ -571,6 +649,11 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                 float4 box = (E.traj_len % FTL_TRAJ_BLOCK == 0) ? make_float4(lpx, lpy, lpx, lpy) : *bb;
                 box.x = fminf(box.x, lpx); box.y = fminf(box.y, lpy); box.z = fmaxf(box.z, lpx); box.w = fmaxf(box.w, lpy);
                 *bb = box; if (P.bb_in_lds) s_bb[E.traj_len / FTL_TRAJ_BLOCK] = box;
+            }
+            {   // the new point enters the distance bounds
+                float ax = lpx - fpx, ay = lpy - fpy;
+                float ad = sqrtf(ax * ax + ay * ay) * 0.999999f - 1e-3f;
+                E.clr_g = fminf(E.clr_g, ad); E.clr_a = fminf(E.clr_a, ad);
             }
             E.traj_len += 1;
         } else E.error |= FTL_ERR_TRAJ_OVERFLOW;
@@ -605,6 +688,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     E.step_count += 1;
     if (E.step_count > c.max_steps) { i0 = FTL_MISSION_FINISHED_BY_TIME; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_MOVING; E.done = 1; }
     reward = c.aggregate_reward ? E.overall_reward : res;
+    FTL_TIC(3);
 }
 
 // ---- LeaderPositionsTracker_v2.scan (sensors.py:243-327), one env per group; the sequential parts (numpy pairwise
@@ -820,6 +904,11 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     float4* s_bb = reinterpret_cast<float4*>(lds + (size_t)EPW * P.cfg.n_static * 16 + (size_t)EPW * 4 + (((size_t)EPW * 4) % 16 ? 16 - ((size_t)EPW * 4) % 16 : 0));
     E.scan_ok = 0; E.near_cnt = 0;
     const Limits L = lane_limits(P.cfg, E.r);
+#ifdef FTL_PROFILE_PATHS
+    if (threadIdx.x < 16) s_cyc[threadIdx.x] = 0;
+    __syncthreads();
+#endif
+    FTL_TIC_INIT;
     if (C.mode == 1) {                                   // reset(): ENV:434-543
         if (C.mask && !C.mask[E.env]) E.valid = false;
         g_load<G>(P, E);                                 // keeps the state of masked-out envs intact (nothing is stored for them)
@@ -831,6 +920,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         __syncthreads();
     } else {                                             // step(action): ENV:908-945
         g_load<G>(P, E);
+        FTL_TIC(4);
         g_build_near<G>(P, E, s_near, s_cnt);
         {
             double a0 = C.action[2 * (size_t)E.env], a1 = C.action[2 * (size_t)E.env + 1];
@@ -853,9 +943,14 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
             for (int b = E.r; b * FTL_TRAJ_BLOCK < E.traj_len; b += G) bbl[b] = bbg[b];
         }
         __syncthreads();
+        FTL_TIC(5);
         int tick = (E.step_count + 1) % P.cfg.trajectory_saving_period;
 #pragma nounroll
+#ifdef FTL_ABLATE_FRAMES
+        for (int f = 0; f < FTL_ABLATE_FRAMES; f++) {
+#else
         for (int f = 0; f < P.cfg.frames_per_step; f++) {                       // ENV:935-936
+#endif
             g_frame<G>(P, E, L, near, bbl, tick, reward, i0, i1, i2);
             __syncthreads();          // an appended trajectory point is read by the other lanes of the group next frame
         }
@@ -863,6 +958,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
             C.out.reward[E.env] = reward; C.out.done[E.env] = (uint8_t)E.done;
             C.out.status[3 * (size_t)E.env] = (uint8_t)i0; C.out.status[3 * (size_t)E.env + 1] = (uint8_t)i1; C.out.status[3 * (size_t)E.env + 2] = (uint8_t)i2;
         }
+        FTL_TIC(9);
         bool go = E.valid && E.done && (C.flags & FTL_STEP_AUTO_RESET);
         if (__ballot(go) != 0ull) {
             if (go) E.episodes += 1;
@@ -870,7 +966,16 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
             __syncthreads();
         }
     }
+    FTL_TIC(6);
+#ifndef FTL_ABLATE_SENSORS
     g_sensors<G>(P, E);                                  // ENV:937 / ENV:541 (tracker part of use_sensors)
+#endif
+    FTL_TIC(7);
     g_write_obs<G>(P, C, E);                             // ENV:938
     g_store<G>(P, E);
+    FTL_TIC(10);
+#ifdef FTL_PROFILE_PATHS
+    __syncthreads();
+    if (threadIdx.x < 16) atomicAdd(&g_cyc[threadIdx.x], s_cyc[threadIdx.x]);
+#endif
 }

@@ -213,6 +213,10 @@ enum {
     FTL_EI_GREEN_TINY, /* the green window may hold a segment so short that f64 sums of segment lengths are no longer exact */
     FTL_EI_RESETS,     /* number of resets of this env slot so far (keys the RNG stream of the episode) */
     FTL_EI_ACC_CONSUMED, /* bit i: entry i of leader_acceleration_regime was consumed -- the reference deletes the key for good (ENV:1170) */
+    /* search caches of _check_agent_position (float bit patterns; they never change a result, only which points are looked at):
+       coordinates of trajectory point FTL_EI_HINT, and lower bounds on the follower's distance to every green point /
+       to every trajectory point */
+    FTL_EI_HINT_X, FTL_EI_HINT_Y, FTL_EI_CLR_GREEN, FTL_EI_CLR_ALL,
     FTL_EI_PAD, FTL_EI_COUNT
 };
 /* indices into the "env_dbl" state field; bear waypoints follow at FTL_ED_BEAR_POINTS + 2*b */

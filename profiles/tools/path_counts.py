@@ -1,0 +1,29 @@
+"""Diagnostic (build with -DFTL_PROFILE_PATHS, FTL_LIB=that .so): branch frequencies of the frame kernel in the
+steady state of the bench workload.  Not part of the product or the tests."""
+import ctypes as C, json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
+from golden_util import GOLDEN, config_for
+from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
+import bench
+z = np.load(GOLDEN + "/pool_B.npz"); meta = json.loads(str(z["meta"]))
+cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=int(z["route_len"].max()))
+n = 65536
+env = VecGame(n, device="cuda:0", config=cfg); pool = ScenarioPool.from_npz(cfg, GOLDEN + "/pool_B.npz", "cuda:0"); env.load_scenarios(pool)
+env.reset((torch.arange(n) % pool.n).to(torch.int32))
+acts = bench.make_actions(cfg, n, 16, 0, torch.device("cuda:0"))
+out = (C.c_ulonglong * 32)()
+names = ["frames", "Gc>2", "hint green hit", "green search", "exact walk", "full search", "blocks scanned (green)", "blocks scanned (full)",
+         "waves w/ green search", "waves w/ full search", "search: in eps", "search: in dev", "search: whole-window eps"]
+for phase, steps in (("steps 0-30", 30), ("steps 30-150", 120), ("steps 150-250", 100)):
+    env.lib.ftl_debug_prof(out, 1)
+    for k in range(steps): env.step(acts[k % 16], auto_reset=True)
+    env.lib.ftl_debug_prof(out, 1)
+    v = list(out); fr = max(v[0], 1)
+    cn = ["frame:move+collide", "frame:green", "frame:agent check (after hint)", "frame:tail", "load", "near+bb stage", "auto-reset", "sensors(tracker)", "frame:hint window", "[frames loop total]", "obs+store", "frame:green search"]
+    cy = v[16:28]; tot = max(sum(cy) - cy[9], 1)
+    print(phase, "cycles share:", " ".join("%s=%.3f" % (cn[i], cy[i] / tot) for i in range(12)), "cycles/wave-step=%.0f" % (tot / (steps * n / 16)))
+    print(phase, " ".join("%s=%.4f" % (names[i], v[i] / fr) for i in range(1, 13)), "waves/frame-wave: green %.3f full %.3f" % (v[8] / (fr / 16), v[9] / (fr / 16)))
+ei = env.state_field("env_int").cpu().numpy()
+from continiousenvironment_follower_leader_amd import abi
+print("traj_len pct", np.percentile(ei[:, abi.EI_TRAJ_LEN], [5, 50, 95]), "green_count pct", np.percentile(ei[:, abi.EI_GREEN_COUNT], [5, 50, 95]), "step_count pct", np.percentile(ei[:, abi.EI_STEP_COUNT], [5, 50, 95]))
