@@ -250,10 +250,20 @@ int ftl_step(ftl_handle* h, const double* action, const ftl_outputs* out, uint32
 }  // extern "C"
 
 #ifdef FTL_PROFILE_PATHS
+extern "C" int ftl_debug_whist(unsigned int* out, int clear) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ftl::g_whist), sizeof(unsigned int) * 128) != hipSuccess) return 1;
+    if (clear) { unsigned int z[128] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ftl::g_whist), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
 extern "C" int ftl_debug_prof(unsigned long long* out, int clear) {
     hipDeviceSynchronize();
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ftl::g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(ftl::g_cyc), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+#ifdef FTL_PROFILE_RAYS
+    if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_rcyc), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (clear) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rcyc), z, sizeof(z)) != hipSuccess) return 1; }
+#endif
     if (clear) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ftl::g_prof), z, sizeof(z)) != hipSuccess) return 1;
                  if (hipMemcpyToSymbol(HIP_SYMBOL(ftl::g_cyc), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;

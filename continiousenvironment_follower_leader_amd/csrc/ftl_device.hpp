@@ -33,7 +33,9 @@
 #define FTL_FRAMES_WPE 3    // min waves per SIMD the register allocator must leave room for (tuned on MI355X)
 #endif
 #ifndef FTL_RAYS_WPE
-#define FTL_RAYS_WPE 6
+#ifndef FTL_RAYS_WPE
+#define FTL_RAYS_WPE 5
+#endif
 #endif
 
 struct FtlDevParams {
@@ -333,6 +335,16 @@ __device__ __forceinline__ bool hit_segment(float cx, float cy, double ex, doubl
 //   (non-negative doubles order like their bit patterns).
 // Phase 4 (one RAY per lane): H minima -> the H output rows of the ray.
 // HM = compile-time number of history accumulators (5 covers every in-repo config, 8 is the ABI cap)
+#ifdef FTL_PROFILE_RAYS       // diagnostic build only (profiles/tools/path_counts.py): cycles per phase of the ray kernel
+__device__ unsigned long long g_rcyc[16];
+__shared__ unsigned long long s_rcyc[16];
+#define FTL_RTIC(slot) do { unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) s_rcyc[slot] += _t - _rprev; _rprev = _t; } while (0)
+#define FTL_RTIC_INIT unsigned long long _rprev = __builtin_readcyclecounter()
+#else
+#define FTL_RTIC(slot) do { } while (0)
+#define FTL_RTIC_INIT do { } while (0)
+#endif
+
 template <int HM>
 __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -343,6 +355,11 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     if (env >= P.n_envs) return;
     if (C.mode == 1 && C.mask && !C.mask[env]) return;
     const int lane = threadIdx.x;
+#ifdef FTL_PROFILE_RAYS
+    if (lane < 16) s_rcyc[lane] = 0;
+    __syncthreads();
+#endif
+    FTL_RTIC_INIT;
     const int hmax = P.hmax;
     const int nrect_dyn = P.R - 1;      // leader + bears per snapshot
     const int cmask = c.corr_cap - 1;   // corr_cap is a power of two (validated on the host)
@@ -363,7 +380,14 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [total_rays][HM]
     const unsigned long long kInfBits = 0x7fefffffffffffffull;                                       // DBL_MAX: "no hit"
 
+    // Round trip 1: everything that is addressed by the env index alone is requested at once -- the scalars, every ring slot
+    // of the snapshot windows (one word per lane) and of the snapshot rects (one rect per lane); which slots are valid is
+    // sorted out after they have arrived.  Round trip 2 (below): corridor points and the scenario's static rects.
     const int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
+    const int* swp = P.snap_win + (size_t)env * hmax * 4;
+    const int4* srp = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)env * hmax * nrect_dyn;
+    const int swv = lane < hmax * 4 ? swp[lane] : 0;
+    const int4 dynq = lane < hmax * nrect_dyn ? srp[lane] : make_int4(0, 0, 0, 0);
     const int scen = ei[FTL_EI_SCEN], snap_count = ei[FTL_EI_SNAP_COUNT], scan_ok = ei[FTL_EI_SCAN_OK];
     const int newest = (ei[FTL_EI_SNAP_HEAD] == 0 ? hmax : ei[FTL_EI_SNAP_HEAD]) - 1;   // ring slot of the newest snapshot
     const size_t fo = (size_t)env * P.R + 1;            // follower
@@ -372,6 +396,8 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     float* out_base = C.out.lasers + (size_t)env * P.lasers_len;
     const int nsnap = snap_count < hmax ? snap_count : hmax;       // valid snapshots, newest = snap_count-1
     const unsigned all_snaps = (1u << nsnap) - 1u;                  // bit a = age a (nsnap <= 8)
+    const int4* stp = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)scen * c.n_static;
+    const int4 stq = lane < c.n_static ? stp[lane] : make_int4(0, 0, 0, 0);     // static rect of this lane (round trip 2)
 
 #pragma nounroll
     for (int which = 0; which < 2; which++) {
@@ -386,16 +412,13 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         // corridor windows of the valid snapshots as this group of sensors saw them; age a = 0 newest
         int win_lo[HM], win_hi[HM];
         int umin = 0x7fffffff, umax = 0;
-        {
-            const int* sw = P.snap_win + (size_t)env * hmax * 4;
 #pragma unroll
-            for (int a = 0; a < HM; a++) {
-                win_lo[a] = 0; win_hi[a] = 0;
-                if (a < nsnap) {
-                    int slot = newest - a; slot += slot < 0 ? hmax : 0;
-                    win_lo[a] = sw[4 * slot + 2 * which]; win_hi[a] = sw[4 * slot + 2 * which + 1];
-                    umin = min(umin, win_lo[a]); umax = max(umax, win_hi[a]);
-                }
+        for (int a = 0; a < HM; a++) {
+            win_lo[a] = 0; win_hi[a] = 0;
+            if (a < nsnap) {
+                int slot = newest - a; slot += slot < 0 ? hmax : 0;
+                win_lo[a] = __builtin_amdgcn_readlane(swv, 4 * slot + 2 * which); win_hi[a] = __builtin_amdgcn_readlane(swv, 4 * slot + 2 * which + 1);   // wave-uniform -> SGPRs
+                umin = min(umin, win_lo[a]); umax = max(umax, win_hi[a]);
             }
         }
         __syncthreads();
@@ -405,11 +428,13 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             s_corr[p & cmask] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
         }
         __syncthreads();
+        FTL_RTIC(0);
 
         // ---- phase 1: culled, compacted segment table; sources flattened: statics | snapshot rects | corridor points | caps
         const float reach = lmax + 2.0f;
         const float bx0 = cx - reach, bx1 = cx + reach, by0 = cy - reach, by1 = cy + reach;
         auto push_rect = [&](int cls, int4 q, unsigned sm) {
+            if (sm == 0u) return;
             if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) return;
             int at = (cls == SEG_STATIC ? 0 : cap_rs) + atomicAdd(&s_cnt[cls], 1);
             s_rect[at] = q; s_rmask[at] = sm;
@@ -424,41 +449,35 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             s_green[at] = make_float4(ax, ay, bx, by); s_gmask[at] = sm;
         };
         {
-            const int n_st = c.n_static, n_dy = nsnap * nrect_dyn, n_co = max(umax - 1 - umin, 0), n_gr = nsnap;
-            const int n_src = n_st + n_dy + n_co + n_gr;
-            const int4* st = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)scen * c.n_static;
-            const int4* sr = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)env * hmax * nrect_dyn;
-            for (int w = lane; w < n_src; w += FTL_WAVE) {
-                if (w < n_st) {
-                    push_rect(SEG_STATIC, st[w], all_snaps);                  // identical in every snapshot
-                } else if (w < n_st + n_dy) {
-                    // the leader is a static-class object (it sits in game_object_list); bears are the dynamic class
-                    int a = 0, o = w - n_st;
-                    while (o >= nrect_dyn) { o -= nrect_dyn; a++; }
-                    int slot = newest - a; slot += slot < 0 ? hmax : 0;
-                    push_rect(o == 0 ? SEG_STATIC : SEG_DYNAMIC, sr[slot * nrect_dyn + o], 1u << a);
-                } else if (w < n_st + n_dy + n_co) {
-                    // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
-                    int p = umin + (w - n_st - n_dy);
-                    unsigned sm = 0;
+            push_rect(SEG_STATIC, stq, lane < c.n_static ? all_snaps : 0u);     // identical in every snapshot
+            for (int w = lane + FTL_WAVE; w < c.n_static; w += FTL_WAVE) push_rect(SEG_STATIC, stp[w], all_snaps);
+            {   // snapshot rects: lane = ring slot * nrect_dyn + object; the leader (object 0) is a static-class object (it
+                // sits in game_object_list), bears are the dynamic class
+                int slot = lane / nrect_dyn, o = lane - slot * nrect_dyn;
+                int a = newest - slot; a += a < 0 ? hmax : 0;
+                push_rect(o == 0 ? SEG_STATIC : SEG_DYNAMIC, dynq, (lane < hmax * nrect_dyn && a < nsnap) ? 1u << a : 0u);
+            }
+            // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
+            for (int p = umin + lane; p < umax - 1; p += FTL_WAVE) {
+                unsigned sm = 0;
 #pragma unroll
-                    for (int a = 0; a < HM; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
-                    if (sm) {
-                        float4 u = s_corr[p & cmask], v = s_corr[(p + 1) & cmask];
-                        push_corr(p, 0, u.x, u.y, v.x, v.y, sm);      // right border
-                        push_corr(p, 1, u.z, u.w, v.z, v.w, sm);      // left border
-                    }
-                } else {
-                    // green-zone end caps of one snapshot (sensors.py:648-650)
-                    int a = w - n_st - n_dy - n_co, lo = 0, hi = 0;
-#pragma unroll
-                    for (int j = 0; j < HM; j++) if (j == a) { lo = win_lo[j]; hi = win_hi[j]; }
-                    float4 u = s_corr[lo & cmask], v = s_corr[(hi - 1) & cmask];
-                    push_green(u.x, u.y, u.z, u.w, 1u << a);
-                    push_green(v.x, v.y, v.z, v.w, 1u << a);
+                for (int a = 0; a < HM; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
+                if (sm) {
+                    float4 u = s_corr[p & cmask], v = s_corr[(p + 1) & cmask];
+                    push_corr(p, 0, u.x, u.y, v.x, v.y, sm);      // right border
+                    push_corr(p, 1, u.z, u.w, v.z, v.w, sm);      // left border
                 }
             }
+            if (lane < nsnap) {     // green-zone end caps of snapshot age `lane` (sensors.py:648-650)
+                int lo = 0, hi = 0;
+#pragma unroll
+                for (int j = 0; j < HM; j++) if (j == lane) { lo = win_lo[j]; hi = win_hi[j]; }
+                float4 u = s_corr[lo & cmask], v = s_corr[(hi - 1) & cmask];
+                push_green(u.x, u.y, u.z, u.w, 1u << lane);
+                push_green(v.x, v.y, v.z, v.w, 1u << lane);
+            }
         }
+        FTL_RTIC(1);
         // ---- phase 2: ray ends of every sensor of this group + accumulators ------------------------------------------------
         {
             int base = 0;
@@ -512,6 +531,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                         rb += c.lasers[k].count;
                     }
                 }
+                FTL_RTIC(3);
                 int i0 = 0, cnt = 0;
                 float4 sg = make_float4(0.f, 0.f, 0.f, 0.f); unsigned sm = 0;
                 const float fN = (float)N;
@@ -552,6 +572,11 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                         cnt = cnt > N ? N : cnt;
                     }
                 }
+                FTL_RTIC(4);
+#ifdef FTL_PROFILE_RAYS
+                if (threadIdx.x == 0) { s_rcyc[8] += 1; }
+                { int mc = cnt; for (int o = 32; o >= 1; o >>= 1) mc = max(mc, __shfl_xor(mc, o)); int ni = __popcll(__ballot(m >= 0)); int sc = cnt; for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o); if (threadIdx.x == 0) { s_rcyc[9] += mc; s_rcyc[10] += sc; s_rcyc[11] += ni; } }
+#endif
                 for (int t = 0; t < cnt; t++) {
                     int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
                     const double2 e = s_ray[rbase + i];
@@ -564,6 +589,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 }
             }
         }
+        FTL_RTIC(5);
         __syncthreads();
         // ---- phase 4: rows, oldest first, newest last (sensors.py:896-901); rows older than the first scan and rays without a
         // hit read |end - origin| (sensors.py:925-930).  pad_sectors (sensors.py:932-953) spreads a row over four N-wide
@@ -610,5 +636,10 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 base += N;
             }
         }
+        FTL_RTIC(6);
     }
+#ifdef FTL_PROFILE_RAYS
+    __syncthreads();
+    if (lane < 16) atomicAdd(&g_rcyc[lane], s_rcyc[lane]);
+#endif
 }

@@ -63,6 +63,7 @@ __device__ unsigned long long g_prof[16];
 #define FTL_PROF(slot, cond, n) do { if (cond) atomicAdd(&g_prof[slot], (unsigned long long)(n)); } while (0)
 #endif
 __device__ unsigned long long g_cyc[16];
+__device__ unsigned int g_whist[2][64];             // wave lifetime histogram (bins of 4096 cycles), [did a reset]
 __shared__ unsigned long long s_cyc[16];           // per-wave accumulators, flushed once at the end of the kernel
 #define FTL_TIC(slot) do { unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) s_cyc[slot] += _t - _tprev; _tprev = _t; } while (0)
 #define FTL_TIC_INIT unsigned long long _tprev = __builtin_readcyclecounter()
@@ -558,6 +559,9 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         else if (h_green && hd2 < dev2_lo && E.clr_g > eps_hi) fast = 2;                // none within epsilon, one within max_dev
         else if (E.clr_g > far_hi) fast = (E.clr_a > eps_hi) ? 3 : (hd2 < eps2_lo ? 4 : 0);   // no green point in reach
         FTL_PROF(2, E.valid && r == 0 && fast != 0, 1);
+        FTL_PROF(13, E.valid && r == 0 && fast == 0 && h_green && hd2 < dev2_lo, 1);
+        FTL_PROF(14, E.valid && r == 0 && fast == 0 && !(h_green && hd2 < dev2_lo) && E.clr_g <= far_hi, 1);
+        FTL_PROF(15, E.valid && r == 0 && fast == 0 && !(h_green && hd2 < dev2_lo) && E.clr_g > far_hi, 1);
         if (fast == 1) { E.is_on_trace = 1; E.is_in_box = 1; }
         else if (fast == 2) { E.is_in_box = 1; }
         else if (fast == 4) { E.is_on_trace = 1; }
@@ -961,6 +965,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         FTL_TIC(9);
         bool go = E.valid && E.done && (C.flags & FTL_STEP_AUTO_RESET);
         if (__ballot(go) != 0ull) {
+#ifdef FTL_PROFILE_PATHS
+            if (threadIdx.x == 0) s_cyc[12] = 1;
+#endif
             if (go) E.episodes += 1;
             g_reset<G>(P, E, go ? (E.scen + P.n_envs) % P.scen.n_scenarios : E.scen, go);
             __syncthreads();
@@ -977,5 +984,10 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
 #ifdef FTL_PROFILE_PATHS
     __syncthreads();
     if (threadIdx.x < 16) atomicAdd(&g_cyc[threadIdx.x], s_cyc[threadIdx.x]);
+    if (threadIdx.x == 0 && C.mode != 1) {
+        unsigned long long tot = 0; for (int i = 0; i < 11; i++) if (i != 9) tot += s_cyc[i];
+        int bin = (int)(tot >> 12); bin = bin > 63 ? 63 : bin;
+        atomicAdd(&g_whist[s_cyc[12] ? 1 : 0][bin], 1u);
+    }
 #endif
 }

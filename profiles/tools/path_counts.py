@@ -12,18 +12,31 @@ n = 65536
 env = VecGame(n, device="cuda:0", config=cfg); pool = ScenarioPool.from_npz(cfg, GOLDEN + "/pool_B.npz", "cuda:0"); env.load_scenarios(pool)
 env.reset((torch.arange(n) % pool.n).to(torch.int32))
 acts = bench.make_actions(cfg, n, 16, 0, torch.device("cuda:0"))
-out = (C.c_ulonglong * 32)()
-names = ["frames", "Gc>2", "hint green hit", "green search", "exact walk", "full search", "blocks scanned (green)", "blocks scanned (full)",
-         "waves w/ green search", "waves w/ full search", "search: in eps", "search: in dev", "search: whole-window eps"]
+out = (C.c_ulonglong * 48)()
+names = ["frames", "Gc>2", "fast path", "green search", "exact walk", "full search", "blocks scanned (green)", "blocks scanned (full)",
+         "waves w/ green search", "waves w/ full search", "search: in eps", "search: in dev", "search: whole-window eps", "fallback: dev-band, eps unproven", "fallback: green bound <= far", "fallback: all bound <= eps"]
 for phase, steps in (("steps 0-30", 30), ("steps 30-150", 120), ("steps 150-250", 100)):
-    env.lib.ftl_debug_prof(out, 1)
+    env.lib.ftl_debug_prof(out, 1); env.lib.ftl_debug_whist((C.c_uint * 128)(), 1)
     for k in range(steps): env.step(acts[k % 16], auto_reset=True)
     env.lib.ftl_debug_prof(out, 1)
     v = list(out); fr = max(v[0], 1)
     cn = ["frame:move+collide", "frame:green", "frame:agent check (after hint)", "frame:tail", "load", "near+bb stage", "auto-reset", "sensors(tracker)", "frame:hint window", "[frames loop total]", "obs+store", "frame:green search"]
     cy = v[16:28]; tot = max(sum(cy) - cy[9], 1)
     print(phase, "cycles share:", " ".join("%s=%.3f" % (cn[i], cy[i] / tot) for i in range(12)), "cycles/wave-step=%.0f" % (tot / (steps * n / 16)))
-    print(phase, " ".join("%s=%.4f" % (names[i], v[i] / fr) for i in range(1, 13)), "waves/frame-wave: green %.3f full %.3f" % (v[8] / (fr / 16), v[9] / (fr / 16)))
+    rc = v[32:48]
+    if sum(rc[:8]):
+        rn = ["stage corridor", "phase1 table", "phase2 ray ends", "phase3 decode", "phase3 arcs", "phase3 ray tests", "phase4 rows"]
+        rt = sum(rc[:7])
+        print(phase, "RAYS cycles share:", " ".join("%s=%.3f" % (rn[i], rc[i] / rt) for i in range(7)), "cycles/env-step=%.0f" % (rt / (steps * n)),
+              "chunks/env-step=%.2f max-cnt/chunk=%.2f sum-cnt/chunk=%.1f items/chunk=%.1f" % (rc[8] / (steps * n), rc[9] / max(rc[8], 1), rc[10] / max(rc[8], 1), rc[11] / max(rc[8], 1)))
+    print(phase, " ".join("%s=%.4f" % (names[i], v[i] / fr) for i in range(1, 16)), "waves/frame-wave: green %.3f full %.3f" % (v[8] / (fr / 16), v[9] / (fr / 16)))
+wh = (C.c_uint * 128)()
+env.lib.ftl_debug_whist(wh, 0)
+wh = np.array(list(wh)).reshape(2, 64)
+for k, nm in enumerate(("no reset", "with reset")):
+    tot = wh[k].sum(); cs = np.cumsum(wh[k]) / max(tot, 1)
+    print("frame-kernel wave lifetime (last phase), %s: waves=%d mean=%.0f kcyc p10=%d p50=%d p90=%d p99=%d max=%d (x4096 cycles)" % (
+        nm, tot, (wh[k] * (np.arange(64) + 0.5) * 4.096).sum() / max(tot, 1), np.searchsorted(cs, 0.1), np.searchsorted(cs, 0.5), np.searchsorted(cs, 0.9), np.searchsorted(cs, 0.99), np.nonzero(wh[k])[0].max() if tot else 0))
 ei = env.state_field("env_int").cpu().numpy()
 from continiousenvironment_follower_leader_amd import abi
 print("traj_len pct", np.percentile(ei[:, abi.EI_TRAJ_LEN], [5, 50, 95]), "green_count pct", np.percentile(ei[:, abi.EI_GREEN_COUNT], [5, 50, 95]), "step_count pct", np.percentile(ei[:, abi.EI_STEP_COUNT], [5, 50, 95]))
