@@ -33,9 +33,7 @@
 #define FTL_FRAMES_WPE 3    // min waves per SIMD the register allocator must leave room for (tuned on MI355X)
 #endif
 #ifndef FTL_RAYS_WPE
-#ifndef FTL_RAYS_WPE
-#define FTL_RAYS_WPE 5
-#endif
+#define FTL_RAYS_WPE 5      // 96 VGPRs; LDS (7 KB per env) caps the CU at ~22 waves anyway
 #endif
 
 struct FtlDevParams {
@@ -335,6 +333,20 @@ __device__ __forceinline__ bool hit_segment(float cx, float cy, double ex, doubl
 //   (non-negative doubles order like their bit patterns).
 // Phase 4 (one RAY per lane): H minima -> the H output rows of the ray.
 // HM = compile-time number of history accumulators (5 covers every in-repo config, 8 is the ABI cap)
+// atan2 for the candidate-ray arc of phase 3 only: |error| <= 2e-5 rad (Abramowitz-Stegun 4.4.47 polynomial on [0,1] +
+// octant folding), two orders of magnitude inside the arc slack (>= 0.01 rad) that absorbs it.  Never used for a value
+// that reaches an output.
+__device__ __forceinline__ float arc_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
+    const float a = hi > 0.0f ? __fdividef(lo, hi) : 0.0f;
+    const float t = a * a;
+    float r = a * (0.9998660f + t * (-0.3302995f + t * (0.1801410f + t * (-0.0851330f + t * 0.0208351f))));
+    r = ay > ax ? 1.5707963267948966f - r : r;
+    r = x < 0.0f ? 3.141592653589793f - r : r;
+    return y < 0.0f ? -r : r;
+}
+
 #ifdef FTL_PROFILE_RAYS       // diagnostic build only (profiles/tools/path_counts.py): cycles per phase of the ray kernel
 __device__ unsigned long long g_rcyc[16];
 __shared__ unsigned long long s_rcyc[16];
@@ -551,15 +563,16 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     // candidate rays: the arc [uA, uB] the segment subtends, in units of the ray spacing from ray 0
                     const float inv_step = fN * 0.15915494309189535f;          // N / (2 pi)
                     float ax = sg.x - cx, ay = sg.y - cy, bx = sg.z - cx, by = sg.w - cy;
-                    float uA = (atan2f(ay, ax) - phi0) * inv_step, uB = (atan2f(by, bx) - phi0) * inv_step;
-                    uA -= floorf(uA / fN) * fN; uB -= floorf(uB / fN) * fN;          // into [0, N)
+                    float uA = (arc_atan2(ay, ax) - phi0) * inv_step, uB = (arc_atan2(by, bx) - phi0) * inv_step;
+                    const float invN = __fdividef(1.0f, fN);
+                    uA -= floorf(uA * invN) * fN; uB -= floorf(uB * invN) * fN;      // into [0, N) (an ulp outside is absorbed by the wrap below)
                     float diff = uB - uA; if (diff < 0.0f) diff += fN;
                     float start = uA, wd = diff;
                     if (diff > 0.5f * fN) { start = uB; wd = fN - diff; }
                     // closest approach of the segment to the follower
                     float ex_ = bx - ax, ey_ = by - ay;
                     float l2 = ex_ * ex_ + ey_ * ey_;
-                    float tt = l2 > 0.0f ? fminf(fmaxf(-(ax * ex_ + ay * ey_) / l2, 0.0f), 1.0f) : 0.0f;
+                    float tt = l2 > 0.0f ? fminf(fmaxf(__fdividef(-(ax * ex_ + ay * ey_), l2), 0.0f), 1.0f) : 0.0f;   // culling only: 2 px of slack below
                     float nx = ax + tt * ex_, ny = ay + tt * ey_;
                     float dmin2 = nx * nx + ny * ny;
                     const float reachf = lenf + 2.0f;
