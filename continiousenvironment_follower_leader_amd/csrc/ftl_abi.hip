@@ -101,7 +101,8 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         P.rays_k[k] = rays; rays += cfg->lasers[k].count;
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
-    P.bb_in_lds = ((size_t)(FTL_WAVE / (P.R <= 4 ? 4 : 8)) * (cfg->traj_cap / FTL_TRAJ_BLOCK) * 16 <= 12 * 1024) ? 1 : 0;
+    // the frame kernel stages at most 48 block boxes per env (registers in flight) and 12 KB per wave
+    P.bb_in_lds = (cfg->traj_cap / FTL_TRAJ_BLOCK <= 48 && (size_t)(FTL_WAVE / (P.R <= 4 ? 4 : 8)) * (cfg->traj_cap / FTL_TRAJ_BLOCK) * 16 <= 12 * 1024) ? 1 : 0;
     {   // row width / common history of the fused sensorPrev output
         int w = 0, hcommon = cfg->n_lasers ? cfg->lasers[0].history : 0;
         for (int k = 0; k < cfg->n_lasers; k++) { P.pol_off[k] = w; w += cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1); if (cfg->lasers[k].history != hcommon) hcommon = -1; }

@@ -228,12 +228,20 @@ __device__ __forceinline__ void g_build_near(const FtlDevParams& P, GCtx& E, int
     if (E.valid) {
         const int4* src = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)E.scen * c.n_static;
         int4* dst = s_near + (size_t)E.slot * c.n_static;
-        for (int s = E.r; s < c.n_static; s += G) {
-            int4 q = src[s];
-            float x0 = (float)q.x, x1 = (float)(q.x + q.z), y0 = (float)q.y, y1 = (float)(q.y + q.w);
-            bool nl = !(x1 < lpx - ml || x0 > lpx + ml || y1 < lpy - ml || y0 > lpy + ml);
-            bool nf = !(x1 < fpx - mf || x0 > fpx + mf || y1 < fpy - mf || y0 > fpy + mf);
-            if (nl || nf) dst[atomicAdd(&s_cnt[E.slot], 1)] = q;
+        constexpr int SU = 8;                            // rects per lane in flight at once
+        for (int s0 = 0; s0 < c.n_static; s0 += SU * G) {
+            int4 qv[SU];
+#pragma unroll
+            for (int k = 0; k < SU; k++) { const int s = s0 + k * G + E.r; qv[k] = s < c.n_static ? src[s] : make_int4(0, 0, 0, 0); }
+#pragma unroll
+            for (int k = 0; k < SU; k++) {
+                const int s = s0 + k * G + E.r;
+                const int4 q = qv[k];
+                float x0 = (float)q.x, x1 = (float)(q.x + q.z), y0 = (float)q.y, y1 = (float)(q.y + q.w);
+                bool nl = !(x1 < lpx - ml || x0 > lpx + ml || y1 < lpy - ml || y0 > lpy + ml);
+                bool nf = !(x1 < fpx - mf || x0 > fpx + mf || y1 < fpy - mf || y0 > fpy + mf);
+                if (s < c.n_static && (nl || nf)) dst[atomicAdd(&s_cnt[E.slot], 1)] = q;
+            }
         }
     }
     __syncthreads();
@@ -925,27 +933,38 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     } else {                                             // step(action): ENV:908-945
         g_load<G>(P, E);
         FTL_TIC(4);
-        g_build_near<G>(P, E, s_near, s_cnt);
-        {
-            double a0 = C.action[2 * (size_t)E.env], a1 = C.action[2 * (size_t)E.env + 1];
-            if (E.r == 1) {
-                command_forward(E.rb, L, a0);                                   // ENV:927
-                if (a1 < 0) command_turn(E.rb, L, fabs(a1), -1);                // ENV:928-933
-                else if (a1 > 0) command_turn(E.rb, L, a1, 1);
-                else command_turn(E.rb, L, 0, 0);
+        // One memory round trip for everything the frames need besides the state: the action, the scenario's static rects
+        // (culled into the near list) and this env's trajectory block boxes are all requested before anything is waited for.
+        const double a0 = C.action[2 * (size_t)E.env], a1 = C.action[2 * (size_t)E.env + 1];
+        const int nblk = P.cfg.traj_cap / FTL_TRAJ_BLOCK;
+        float4* bbg = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * nblk;
+        float4* bbl = bbg;
+        constexpr int BBU = 48 / G;                      // bb_in_lds guarantees nblk <= 48 (host side)
+        float4 bbv[BBU];
+        if (P.bb_in_lds) {
+#pragma unroll
+            for (int k = 0; k < BBU; k++) {
+                const int b = k * G + E.r;
+                bbv[k] = (b * FTL_TRAJ_BLOCK < E.traj_len) ? bbg[b] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+        g_build_near<G>(P, E, s_near, s_cnt);
+        if (P.bb_in_lds) {
+            bbl = s_bb + (size_t)E.slot * nblk;
+#pragma unroll
+            for (int k = 0; k < BBU; k++) {
+                const int b = k * G + E.r;
+                if (b * FTL_TRAJ_BLOCK < E.traj_len) bbl[b] = bbv[k];
+            }
+        }
+        if (E.r == 1) {
+            command_forward(E.rb, L, a0);                                   // ENV:927
+            if (a1 < 0) command_turn(E.rb, L, fabs(a1), -1);                // ENV:928-933
+            else if (a1 > 0) command_turn(E.rb, L, a1, 1);
+            else command_turn(E.rb, L, 0, 0);
         }
         double reward = 0; int i0 = 0, i1 = 0, i2 = 0;
         const int4* near = s_near + (size_t)E.slot * P.cfg.n_static;
-        const int nblk = P.cfg.traj_cap / FTL_TRAJ_BLOCK;
-        // this env's block bounding boxes: staged in LDS for the step when they fit (long-horizon configs read them
-        // from global memory instead -- the LDS copy is an optimisation, not a requirement)
-        float4* bbg = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * nblk;
-        float4* bbl = bbg;
-        if (P.bb_in_lds) {
-            bbl = s_bb + (size_t)E.slot * nblk;
-            for (int b = E.r; b * FTL_TRAJ_BLOCK < E.traj_len; b += G) bbl[b] = bbg[b];
-        }
         __syncthreads();
         FTL_TIC(5);
         int tick = (E.step_count + 1) % P.cfg.trajectory_saving_period;
