@@ -12,8 +12,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libftl_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", "ftl_abi.hip"), os.path.join(_PKG, "csrc", "ftl_device.hpp"),
-           os.path.join(_PKG, "csrc", "ftl_frames_group.hpp"),
+           os.path.join(_PKG, "csrc", "ftl_frames_group.hpp"), os.path.join(_PKG, "csrc", "ftl_scenario.cpp"),
            os.path.join(_ROOT, "include", "ftl.h")]
+# translation units: the device code + C-ABI, and the host-only scenario generator (reset-time, no GPU code)
+UNITS = [os.path.join(_PKG, "csrc", "ftl_abi.hip"), os.path.join(_PKG, "csrc", "ftl_scenario.cpp")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the arithmetic must follow the reference operation by operation (no implicit FMA)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
@@ -25,7 +27,7 @@ def build(force=False, verbose=False):
     """Compile the HIP library in-tree for gfx950 (works without a GPU: hipcc cross-compiles)."""
     stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in SOURCES)
     if force or stale:
-        cmd = [HIPCC] + HIPCC_FLAGS + ["-o", SO_PATH, SOURCES[0]]
+        cmd = [HIPCC] + HIPCC_FLAGS + ["-pthread", "-o", SO_PATH] + UNITS
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=os.path.join(_PKG, "csrc"))
@@ -65,6 +67,10 @@ def load():
     lib.ftl_load_scenarios.argtypes = [vp, C.POINTER(abi.Scenarios)]
     lib.ftl_reset.argtypes = [vp, vp, vp, C.POINTER(abi.Outputs), vp]
     lib.ftl_step.argtypes = [vp, vp, C.POINTER(abi.Outputs), u32, vp]
+    lib.ftl_generate_scenarios.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.ScenParams), vp, i32, i32,
+                                           C.POINTER(abi.Scenarios), vp]
+    lib.ftl_generate_scenarios.restype = C.c_int
+    lib.ftl_sizeof_scen_params.restype = C.c_size_t
     for n in ("ftl_sizeof_config", "ftl_sizeof_scenarios", "ftl_sizeof_outputs"):
         getattr(lib, n).restype = C.c_size_t
     _LIB = lib
@@ -72,7 +78,7 @@ def load():
 
 
 EXPORTS = ("ftl_create", "ftl_destroy", "ftl_lasers_len", "ftl_get_config", "ftl_state_bytes", "ftl_bind_state",
-           "ftl_state_field", "ftl_load_scenarios", "ftl_reset", "ftl_step", "ftl_last_error")
+           "ftl_state_field", "ftl_load_scenarios", "ftl_reset", "ftl_step", "ftl_last_error", "ftl_generate_scenarios")
 
 
 def check(rc, lib=None):

@@ -96,6 +96,21 @@ class Scenarios(C.Structure):
                 ("init_traj", C.c_void_p), ("init_traj_len", C.c_void_p)]
 
 
+class ScenParams(C.Structure):
+    """ftl_scen_params: what the reset-time scenario generator needs of Game(**kwargs)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("step_grid", C.c_int32), ("obstacle_number", C.c_int32),
+                ("add_obstacles", C.c_int32), ("add_bear", C.c_int32), ("bear_number", C.c_int32), ("bear_behind", C.c_int32),
+                ("multiple_end_points", C.c_int32), ("path_finding_iterations", C.c_int32),
+                ("bridge_gap", C.c_int32), ("bridge_width", C.c_int32),
+                ("trajectory_saving_period", C.c_int32), ("_pad", C.c_int32),
+                ("min_distance", C.c_double), ("max_distance", C.c_double),
+                ("leader_pos_epsilon", C.c_double), ("leader_margin", C.c_double),
+                ("leader_w", C.c_double), ("leader_h", C.c_double), ("leader_max_speed", C.c_double)]
+
+
+SCEN_FOUND, SCEN_DONE_AT_RESET, SCEN_ROUTE_OVERFLOW, SCEN_TRAJ_OVERFLOW, SCEN_REF_RAISES = 1, 2, 4, 8, 16
+
+
 class Outputs(C.Structure):
     _fields_ = [("obs_num", C.c_void_p), ("lasers", C.c_void_p), ("target", C.c_void_p),
                 ("reward", C.c_void_p), ("done", C.c_void_p), ("status", C.c_void_p), ("policy_obs", C.c_void_p)]

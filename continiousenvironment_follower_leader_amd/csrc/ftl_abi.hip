@@ -76,6 +76,7 @@ const char* ftl_last_error(void) { return g_err.c_str(); }
 size_t ftl_sizeof_config(void) { return sizeof(ftl_config); }
 size_t ftl_sizeof_scenarios(void) { return sizeof(ftl_scenarios); }
 size_t ftl_sizeof_outputs(void) { return sizeof(ftl_outputs); }
+size_t ftl_sizeof_scen_params(void) { return sizeof(ftl_scen_params); }
 
 int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle** out) {
     if (!cfg || !out) return fail(FTL_E_INVALID, "null argument");

@@ -1,0 +1,361 @@
+// ftl_generate_scenarios -- the scenario part of the reference's Game.reset(), host side.
+//
+// Follows, in the reference's order of `random` draws (so that python seed s reproduces `game.seed(s); game.reset()`):
+//   _create_robots                ENV:545-595     leader start by randrange, follower placed behind it (first draw)
+//   _create_obstacles             ENV:613-677     two bridge walls, obstacle_number 50x50 rocks by rejection sampling
+//   generate_finish_point         ENV:1614-1630   rejection sampling against every game object
+//   generate_trajectory_dstar     ENV:1493-1612   utils/dstar.py:84-210 -- a first D* run is Dijkstra from the goal
+//   _create_dyn_obs/_reset_pose_bear  ENV:687-720, 761-770
+//   _pos_follower_behind_leader   ENV:598-611     second follower draw, relative to the leader's new direction
+//   initial leader_factual_trajectory  ENV:533-539  np.linspace(float32, float32) -> float32
+// Third-party semantics restated here: CPython 3.10 `random` (MT19937 init_by_array, getrandbits, _randbelow_with_getrandbits,
+// randrange), pygame.Rect integer truncation (tests/golden/gen/standins, parity unpinned at that boundary as in DESIGN.md 3),
+// numpy float32 linspace, scipy euclidean on float32 operands.
+// Not reproducible: which of several equal-cost routes dstar.py returns (min() over a set of objects hashed by id).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <queue>
+#include <thread>
+#include <vector>
+
+#include "../../include/ftl.h"
+
+namespace {
+
+// ---- CPython random.Random (Modules/_randommodule.c, Lib/random.py) ---------------------------------------------------
+struct PyRandom {
+    uint32_t mt[624];
+    int idx;
+    void init_genrand(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    void init_by_array(const uint32_t* key, int len) {
+        init_genrand(19650218u);
+        int i = 1, j = 0;
+        for (int k = (624 > len ? 624 : len); k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            i++; j++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (j >= len) j = 0;
+        }
+        for (int k = 623; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            i++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    void seed(int64_t a) {                       // random.seed(int): key = 32-bit little-endian digits of abs(a)
+        uint64_t u = a < 0 ? (uint64_t)(-(a + 1)) + 1u : (uint64_t)a;
+        uint32_t key[2] = {(uint32_t)u, (uint32_t)(u >> 32)};
+        init_by_array(key, key[1] ? 2 : 1);
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            int kk;
+            for (kk = 0; kk < 624 - 397; kk++) { uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            for (; kk < 623; kk++) { uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+            mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+    uint32_t randbelow(uint32_t n) {             // _randbelow_with_getrandbits, n < 2^32
+        int k = 0; for (uint32_t v = n; v; v >>= 1) k++;
+        uint32_t r = next() >> (32 - k);
+        while (r >= n) r = next() >> (32 - k);
+        return r;
+    }
+    // randrange(start, stop, step) with positive step; ok=false where CPython raises ValueError (empty range)
+    long randrange(long start, long stop, long step, bool& ok) {
+        long width = stop - start;
+        long n = step == 1 ? width : (width + step - 1) / step;
+        if (n <= 0) { ok = false; return start; }
+        return start + step * (long)randbelow((uint32_t)n);
+    }
+};
+
+struct Rect {
+    int x, y, w, h;
+    int right() const { return x + w; }
+    int bottom() const { return y + h; }
+    bool collidepoint(double px, double py) const { return x <= px && px < x + w && y <= py && py < y + h; }
+};
+// image.get_rect(center=position, width=w, height=h) on an image already scaled to (w, h): CLS:42-50
+inline Rect rect_at(float cx, float cy, int w, int h) { return Rect{(int)cx - (w >> 1), (int)cy - (h >> 1), w, h}; }
+
+inline double angle_correction(double a) { return a >= 360 ? a - 360 : (a < 0 ? 360 + a : a); }   // MISC:6-13
+inline double angle_to_point(double cx, double cy, double tx, double ty) {                         // MISC:16-26
+    const double rx = tx - cx, ry = ty - cy;
+    double res;
+    if (rx > 0) res = atan(ry / rx) * (180.0 / M_PI);
+    else if (rx < 0) res = atan(ry / rx) * (180.0 / M_PI) + 180;
+    else res = 0;
+    return angle_correction(res);
+}
+inline double radians(double d) { return d * (M_PI / 180.0); }
+// scipy.spatial.distance.euclidean on two float32 vectors (oracle/ftl_oracle.c euclid_f32)
+inline double euclid_f32(float ax, float ay, float bx, float by) {
+    float dx = ax - bx, dy = ay - by;
+    return (double)(float)sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+}
+
+// ---- utils/dstar.py: the first run() on a fresh map is Dijkstra from the goal; the route is the parent chain from start.
+// Costs accumulate exactly as there (h_new = x.h + cost, cost = 1.0 or sqrt(2.0) as a double).  Returns false when the walk
+// along the parents cannot reach the goal the way the reference's cannot (goal inside an inflated obstacle).
+struct Grid {
+    int rows, cols;
+    std::vector<uint8_t> obst;
+    bool in(int x, int y) const { return x >= 0 && x < rows && y >= 0 && y < cols; }
+};
+
+bool plan_route(const Grid& g, int sx, int sy, int gx, int gy, int max_iterat, std::vector<int>& rx, std::vector<int>& ry) {
+    rx.clear(); ry.clear();
+    if (!g.in(sx, sy) || !g.in(gx, gy)) return false;
+    if (sx == gx && sy == gy) return true;                   // `while tmp != end` never runs: empty route
+    // An obstacle goal or start makes every first move cost sys.maxsize: the reference then wanders through modify()
+    // until max_iterat and reports found_target_point = False (pinned against the seeds the golden pool dropped).
+    if (g.obst[(size_t)gx * g.cols + gy] || g.obst[(size_t)sx * g.cols + sy]) return false;
+    const int N = g.rows * g.cols;
+    const double INF = 1e300;
+    std::vector<double> h((size_t)N, INF);
+    std::vector<int> parent((size_t)N, -1);
+    std::vector<uint8_t> closed((size_t)N, 0);
+    struct Item { double k; uint32_t seq; int id; };
+    struct Cmp { bool operator()(const Item& a, const Item& b) const { return a.k > b.k || (a.k == b.k && a.seq > b.seq); } };
+    std::priority_queue<Item, std::vector<Item>, Cmp> open;
+    uint32_t seq = 0;
+    const int goal = gx * g.cols + gy, start = sx * g.cols + sy;
+    h[(size_t)goal] = 0.0;
+    open.push(Item{0.0, seq++, goal});
+    const double SQ2 = sqrt(2.0);
+    while (!open.empty()) {
+        Item it = open.top(); open.pop();
+        if (closed[(size_t)it.id] || it.k != h[(size_t)it.id]) continue;
+        closed[(size_t)it.id] = 1;
+        if (it.id == start) break;
+        const int x = it.id / g.cols, y = it.id % g.cols;
+        for (int i = -1; i <= 1; i++)                            // neighbour order of Map.get_neighbors (dstar.py:62-74)
+            for (int j = -1; j <= 1; j++) {
+                if (!i && !j) continue;
+                const int nx = x + i, ny = y + j;
+                if (!g.in(nx, ny)) continue;
+                const int nid = nx * g.cols + ny;
+                if (g.obst[(size_t)nid] || closed[(size_t)nid]) continue;
+                const double hn = it.k + ((i && j) ? SQ2 : 1.0);
+                if (hn < h[(size_t)nid]) { h[(size_t)nid] = hn; parent[(size_t)nid] = it.id; open.push(Item{hn, seq++, nid}); }
+            }
+    }
+    if (!closed[(size_t)start]) return false;                 // unreachable goal: the reference would never return
+    int cur = start, iter = 0;
+    while (cur != goal) {
+        if (++iter > max_iterat) return false;
+        rx.push_back(cur / g.cols); ry.push_back(cur % g.cols);
+        cur = parent[(size_t)cur];
+        if (cur < 0) return false;
+    }
+    return true;
+}
+
+struct Obj { Rect r; float px, py; int w, h; };             // GameObject: rectangle, float32 start_position, height/width
+
+void generate_one(const ftl_config& c, const ftl_scen_params& sp, int64_t seed, int idx, const ftl_scenarios& out, uint8_t* status) {
+    const int R = 2 + c.n_bears;
+    PyRandom rnd; rnd.seed(seed);
+    bool ok = true;
+    unsigned st = 0;
+    const int W = sp.width, H = sp.height, sg = sp.step_grid;
+    // ---- _create_robots (ENV:545-595)
+    const long lx = rnd.randrange((long)(W / 2.0 + sp.max_distance), (long)(W - sp.max_distance), 10, ok);
+    const long ly = rnd.randrange((long)sp.max_distance, (long)(H - sp.max_distance), 10, ok);
+    const double ldir0 = angle_to_point((double)lx, (double)ly, (double)(long)(W / 2.0), (double)(long)(H / 2.0));   // np.array(..., dtype=int)
+    const float lpx = (float)lx, lpy = (float)ly;
+    const Rect lrect = rect_at(lpx, lpy, c.leader.img_w, c.leader.img_h);
+    Rect frect0;
+    {
+        const long d = rnd.randrange((long)(sp.min_distance * 1.1), (long)(sp.max_distance * 0.9), 1, ok);
+        const double th = radians(angle_correction(ldir0 + 180));
+        const double fx = (double)d * cos(th) + (double)lx, fy = (double)d * sin(th) + (double)ly;
+        frect0 = rect_at((float)fx, (float)fy, c.follower.img_w, c.follower.img_h);
+    }
+    // ---- _create_obstacles (ENV:613-677); game_object_list = [leader, follower, wall1, wall2, rocks...]
+    std::vector<Obj> objs;           // statics only, in game_object_list order
+    if (sp.add_obstacles) {
+        const int boh = (H - sp.bridge_gap) / 2;                              // bridge_obstacle_height
+        const float m1x = (float)(W / 2.0), m1y = (float)(boh / 2);
+        const float m2y = (float)((H / 2) + (boh / 2) + (sp.bridge_gap / 2));
+        Obj w1{rect_at(m1x, m1y, sp.bridge_width, boh), m1x, m1y, sp.bridge_width, boh};
+        Obj w2{rect_at(m1x, m2y, sp.bridge_width, boh), m1x, m2y, sp.bridge_width, boh};
+        const int wall_start_x = w1.r.x, wall_end_x = w1.r.right();
+        // pygame.Rect(...) truncates each float argument toward zero
+        const Rect bridge{(int)(wall_start_x - sp.leader_w * 4), (int)(w1.r.bottom() - sp.leader_h * sp.leader_margin),
+                          (int)(w1.r.w + 8 * sp.leader_w), (int)(w2.r.y - w1.r.bottom() + 3 * sp.leader_h)};
+        const int osz = 50;
+        std::vector<Obj> rocks;
+        for (int i = 0; i < sp.obstacle_number && ok; i++) {
+            long gx2, gy2;
+            for (;;) {
+                gx2 = rnd.randrange(130, W - 120, sg, ok); gy2 = rnd.randrange(20, H - 20, sg, ok);
+                if (!ok) break;
+                const double ddx = (double)lpx - (double)gx2, ddy = (double)lpy - (double)gy2;
+                const bool busy = lrect.collidepoint((double)gx2, (double)gy2) || frect0.collidepoint((double)gx2, (double)gy2) ||
+                                  (gx2 >= wall_start_x && gx2 <= wall_end_x) || bridge.collidepoint((double)gx2, (double)gy2) ||
+                                  sqrt(ddx * ddx + ddy * ddy) <= sp.max_distance + osz / 2.0;
+                if (!busy) break;
+            }
+            rocks.push_back(Obj{rect_at((float)gx2, (float)gy2, osz, osz), (float)gx2, (float)gy2, osz, osz});
+        }
+        objs.push_back(w1); objs.push_back(w2);
+        objs.insert(objs.end(), rocks.begin(), rocks.end());
+    }
+    // ---- generate_finish_point (ENV:1614-1630) against [leader, follower (as first placed), statics]
+    auto finish_point = [&](long x0, long y0, long x1, long y1, long& fx, long& fy) {
+        std::vector<Rect> all; all.push_back(lrect); all.push_back(frect0);
+        for (const Obj& o : objs) all.push_back(o.r);
+        for (;;) {
+            fx = rnd.randrange(x0, x1, 10, ok); fy = rnd.randrange(y0, y1, 10, ok);
+            if (!ok) return;
+            bool good = true;
+            for (const Rect& r : all) {
+                if (r.collidepoint((double)fx, (double)fy)) { good = false; continue; }
+                // distance_to_rect (MISC:29-44): corners and edge mid-points, integer coordinates
+                const int qx[8] = {r.x, r.x, r.x + r.w, r.x + r.w, r.x + (r.w >> 1), r.x, r.x + (r.w >> 1), r.x + r.w};
+                const int qy[8] = {r.y, r.y + r.h, r.y, r.y + r.h, r.y, r.y + (r.h >> 1), r.y + r.h, r.y + (r.h >> 1)};
+                double md = INFINITY;
+                for (int k = 0; k < 8; k++) { double dx = (double)(fx - qx[k]), dy = (double)(fy - qy[k]); md = fmin(md, sqrt(dx * dx + dy * dy)); }
+                if (md < sp.leader_pos_epsilon) good = false;
+            }
+            if (good) return;
+        }
+    };
+    long f1x = 0, f1y = 0, f2x = 0, f2y = 0, f3x = 0, f3y = 0;
+    finish_point(20, 20, (long)(W / 2.0), H - 20, f1x, f1y);
+    if (sp.multiple_end_points && ok) {                                       // ENV:470-481
+        if (f1y >= H / 2.0) finish_point(20, 20, W - 20, (long)(H / 2.0), f2x, f2y);
+        else finish_point(20, (long)(H / 2.0), W - 20, H - 20, f2x, f2y);
+        if (ok) {
+            if (f2y >= H / 2.0) finish_point(20, 20, W - 20, (long)(H / 2.0), f3x, f3y);
+            else finish_point(20, (long)(H / 2.0), W - 20, H - 20, f3x, f3y);
+        }
+    }
+    // ---- generate_trajectory_dstar (ENV:1493-1612)
+    std::vector<long> route_x, route_y;
+    bool found = ok;
+    if (ok) {
+        Grid g; g.rows = W / sg; g.cols = H / sg; g.obst.assign((size_t)g.rows * g.cols, 0);
+        const int margin = (int)floor(sp.leader_margin * fmax(sp.leader_w, sp.leader_h) / sg);
+        // order of the reference: rocks, then the two walls (irrelevant for a set of cells)
+        for (const Obj& o : objs) {
+            const int pmx = (int)floorf(o.px / (float)sg), pmy = (int)floorf(o.py / (float)sg);
+            const int hh = (int)floor((o.h / 2.0) / sg) + margin, hw = (int)floor((o.w / 2.0) / sg) + margin;
+            for (int i = pmx - hw; i < pmx + hw; i++)
+                for (int j = pmy - hh; j < pmy + hh; j++)
+                    if (g.in(i, j)) g.obst[(size_t)i * g.cols + j] = 1;
+        }
+        std::vector<int> rx, ry;
+        int sx = (int)(lpx / (float)sg), sy = (int)(lpy / (float)sg);
+        const long gxs[3] = {f1x, f2x, f3x}, gys[3] = {f1y, f2y, f3y};
+        const int runs = sp.multiple_end_points ? 3 : 1;
+        for (int k = 0; k < runs; k++) {
+            const int gx = (int)((double)gxs[k] / sg), gy = (int)((double)gys[k] / sg);
+            // the 2nd and 3rd planner of the reference use the default max_iterat (Dstar(m2), dstar.py:85)
+            const bool f = plan_route(g, sx, sy, gx, gy, k == 0 ? sp.path_finding_iterations : 15000, rx, ry);
+            found = found && f;
+            for (size_t i = 0; i < rx.size(); i++) { route_x.push_back((long)rx[i] * sg); route_y.push_back((long)ry[i] * sg); }
+            sx = gx; sy = gy;
+        }
+    }
+    if (found) st |= FTL_SCEN_FOUND;
+    const int rl = (int)route_x.size();
+    if (rl == 0) st |= FTL_SCEN_DONE_AT_RESET;
+    if (rl == 1) st |= FTL_SCEN_REF_RAISES;
+    // ---- leader direction, follower behind the leader (ENV:506-525, 598-611)
+    double ldir = ldir0;
+    float fpx = lpx, fpy = lpy; double fdir = 0;
+    if (ok) {
+        double tx = (double)lpx, ty = (double)lpy;              // len(trajectory) == 0: cur_target_point = leader.start_position
+        if (rl >= 2) { tx = (double)route_x[1]; ty = (double)route_y[1]; }
+        ldir = angle_to_point((double)lpx, (double)lpy, tx, ty);
+        const long d = rnd.randrange((long)(sp.min_distance * 1.1), (long)(sp.max_distance * 0.9), 1, ok);
+        const double th = angle_correction(ldir + 180);
+        const double fx = (double)d * cos(radians(th)) + (double)lpx, fy = (double)d * sin(radians(th)) + (double)lpy;
+        fdir = angle_to_point(fx, fy, (double)lpx, (double)lpy);
+        fpx = (float)fx; fpy = (float)fy;
+    }
+    // ---- outputs
+    int32_t* srect = const_cast<int32_t*>(out.static_rects) + (size_t)idx * c.n_static * 4;
+    for (int s = 0; s < c.n_static; s++) {
+        Rect r = s < (int)objs.size() ? objs[(size_t)s].r : Rect{0, 0, 0, 0};
+        srect[4 * s] = r.x; srect[4 * s + 1] = r.y; srect[4 * s + 2] = r.w; srect[4 * s + 3] = r.h;
+    }
+    float* rp = const_cast<float*>(out.robot_pos) + (size_t)idx * R * 2;
+    double* rd = const_cast<double*>(out.robot_dir) + (size_t)idx * R;
+    int32_t* rr = const_cast<int32_t*>(out.robot_rect) + (size_t)idx * R * 4;
+    auto put = [&](int r, float x, float y, double dir, Rect q) {
+        rp[2 * r] = x; rp[2 * r + 1] = y; rd[r] = dir; rr[4 * r] = q.x; rr[4 * r + 1] = q.y; rr[4 * r + 2] = q.w; rr[4 * r + 3] = q.h;
+    };
+    put(0, lpx, lpy, ldir, lrect);
+    put(1, fpx, fpy, fdir, rect_at(fpx, fpy, c.follower.img_w, c.follower.img_h));
+    for (int b = 0; b < c.n_bears; b++) {                     // _reset_pose_bear (ENV:761-770); float32 arithmetic on leader.position
+        const float bx = (b % 2 == 0) ? lpx + 150.0f : lpx - 150.0f, by = (b % 2 == 0) ? lpy - 150.0f : lpy + 150.0f;
+        put(2 + b, bx, by, 0.0, rect_at(bx, by, c.bear.img_w, c.bear.img_h));
+    }
+    double* ro = const_cast<double*>(out.route) + (size_t)idx * c.route_cap * 2;
+    if (rl > c.route_cap) st |= FTL_SCEN_ROUTE_OVERFLOW;
+    const int rn = rl < c.route_cap ? rl : c.route_cap;
+    for (int i = 0; i < rn; i++) { ro[2 * i] = (double)route_x[(size_t)i]; ro[2 * i + 1] = (double)route_y[(size_t)i]; }
+    for (int i = rn; i < c.route_cap; i++) { ro[2 * i] = 0; ro[2 * i + 1] = 0; }
+    const_cast<int32_t*>(out.route_len)[idx] = rn;
+    // ---- initial leader_factual_trajectory (ENV:533-539): float32 linspace follower -> leader
+    float* it = const_cast<float*>(out.init_traj) + (size_t)idx * c.init_traj_cap * 2;
+    int n = (int)(euclid_f32(fpx, fpy, lpx, lpy) / (sp.trajectory_saving_period * sp.leader_max_speed));
+    if (n < 0) n = 0;
+    if (n > c.init_traj_cap) { st |= FTL_SCEN_TRAJ_OVERFLOW; n = c.init_traj_cap; }
+    if (n == 1) { it[0] = fpx; it[1] = fpy; }
+    else if (n > 1) {
+        const float div = (float)(n - 1);
+        const float dxx = lpx - fpx, dyy = lpy - fpy;
+        const float stepx = dxx / div, stepy = dyy / div;
+        for (int i = 0; i < n; i++) {
+            it[2 * i] = (stepx == 0) ? ((float)i / div) * dxx + fpx : (float)i * stepx + fpx;
+            it[2 * i + 1] = (stepy == 0) ? ((float)i / div) * dyy + fpy : (float)i * stepy + fpy;
+        }
+        it[2 * (n - 1)] = lpx; it[2 * (n - 1) + 1] = lpy;
+    }
+    for (int i = n; i < c.init_traj_cap; i++) { it[2 * i] = 0; it[2 * i + 1] = 0; }
+    const_cast<int32_t*>(out.init_traj_len)[idx] = n;
+    if (!ok) st = FTL_SCEN_REF_RAISES;                          // an empty randrange: CPython raises ValueError
+    status[idx] = (uint8_t)st;
+}
+
+}  // namespace
+
+extern "C" int ftl_generate_scenarios(const ftl_config* cfg, const ftl_scen_params* sp, const int64_t* seeds, int32_t n,
+                                      int32_t n_threads, const ftl_scenarios* out, uint8_t* status) {
+    if (!cfg || !sp || !seeds || !out || !status || n < 0) return FTL_E_INVALID;
+    if (!out->static_rects || !out->robot_pos || !out->robot_dir || !out->robot_rect || !out->route || !out->route_len ||
+        !out->init_traj || !out->init_traj_len) return FTL_E_INVALID;
+    if (sp->step_grid <= 0 || sp->width <= 0 || sp->height <= 0 || sp->trajectory_saving_period <= 0 || !(sp->leader_max_speed > 0)) return FTL_E_INVALID;
+    if (cfg->n_static != (sp->add_obstacles ? sp->obstacle_number + 2 : 0)) return FTL_E_INVALID;
+    if (cfg->n_bears != (sp->add_bear ? sp->bear_number : 0)) return FTL_E_INVALID;
+    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (T < 1) T = 1;
+    if (T > n) T = n > 0 ? n : 1;
+    std::atomic<int> next(0);
+    auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) generate_one(*cfg, *sp, seeds[i], i, *out, status); };
+    if (T == 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work);
+        for (auto& t : th) t.join();
+    }
+    return FTL_OK;
+}

@@ -59,6 +59,22 @@ class ScenarioPool:
         self.c_struct = s
 
     @classmethod
+    def generate(cls, cfg, seeds, device, n_threads=0):
+        """Pool of the usable scenarios among python seeds ``seeds`` from the host-side generator (scenario.py): what
+        ``game.seed(s); game.reset()`` builds in the reference, without the reference."""
+        from .scenario import generate_scenarios
+        g = generate_scenarios(cfg, seeds, n_threads)
+        keep = np.nonzero(g["usable"])[0]
+        if len(keep) == 0:
+            raise ValueError("no usable scenario among the given seeds")
+        routes = [g["route"][i, :g["route_len"][i]] for i in keep]
+        trajs = [g["init_traj"][i, :g["init_traj_len"][i]] for i in keep]
+        pool = cls(cfg, g["static_rects"][keep], g["robot_pos"][keep], g["robot_dir"][keep], g["robot_rect"][keep],
+                   routes, trajs, device)
+        pool.seeds = g["seed"][keep]
+        return pool
+
+    @classmethod
     def from_npz(cls, cfg, path, device, limit=None):
         z = np.load(path)
         n = len(z["seed"]) if limit is None else min(limit, len(z["seed"]))

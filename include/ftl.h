@@ -150,6 +150,46 @@ typedef struct ftl_scenarios {
     const int32_t* init_traj_len;  /* [P] */
 } ftl_scenarios;
 
+/* ---- reset-time scenario generation (host side, no GPU involved) ------------------------------
+ * The scenario part of Game.reset(): robots (ENV:545-611), bridge walls + rocks by rejection sampling (ENV:613-677),
+ * finish point (ENV:1614-1630), grid route (ENV:1493-1612 on utils/dstar.py:84-210), bears (ENV:687-720, 761-770),
+ * initial leader trajectory (ENV:533-539).  The draws come from a bit-compatible twin of CPython's `random`
+ * (MT19937, seed(int), randrange) so that seed s yields the scenario of `game.seed(s); game.reset()`.
+ * The route is a shortest 8-connected path on the reference's cost model (1 / sqrt 2 per move, inflated obstacle
+ * cells); among equal-cost paths the reference's choice depends on CPython set iteration order over object ids and is
+ * not reproducible -- the generator breaks such ties by insertion order (documented as unpinned in DESIGN.md). */
+typedef struct ftl_scen_params {
+    int32_t width, height;                /* game_width, game_height */
+    int32_t step_grid, obstacle_number;   /* obstacle_number is 0 when add_obstacles is False (ENV:323-324) */
+    int32_t add_obstacles, add_bear, bear_number, bear_behind;
+    int32_t multiple_end_points, path_finding_iterations;
+    int32_t bridge_gap, bridge_width;     /* bridge_size[0], bridge_size[1] (ENV:617-620) */
+    int32_t trajectory_saving_period, _pad;
+    double  min_distance, max_distance;   /* pixels */
+    double  leader_pos_epsilon, leader_margin;
+    double  leader_w, leader_h;           /* the float pixel sizes the reference keeps on the robot (ENV:352-353, CLS:104-105) */
+    double  leader_max_speed;             /* px/frame */
+} ftl_scen_params;
+
+/* per-scenario status bits written by ftl_generate_scenarios */
+#define FTL_SCEN_FOUND        1u   /* found_target_point (ENV:1537): the route reaches the finish point */
+#define FTL_SCEN_DONE_AT_RESET 2u  /* empty route (ENV:508-510) */
+#define FTL_SCEN_ROUTE_OVERFLOW 4u /* route longer than cfg->route_cap: truncated, do not use */
+#define FTL_SCEN_TRAJ_OVERFLOW 8u  /* initial trajectory longer than cfg->init_traj_cap: truncated, do not use */
+#define FTL_SCEN_REF_RAISES  16u   /* the reference's reset() would raise here (one-point route, ENV:513) */
+
+/* Fill `out` (HOST arrays shaped like ftl_scenarios with P = n; cfg gives n_static, R, route_cap, init_traj_cap) with the
+ * scenarios of python seeds seeds[0..n); status[i] gets the FTL_SCEN_* bits of scenario i.  n_threads <= 0: all cores. */
+int ftl_generate_scenarios(const ftl_config* cfg, const ftl_scen_params* sp, const int64_t* seeds, int32_t n,
+                           int32_t n_threads, const ftl_scenarios* out, uint8_t* status);
+
+/* struct sizes as this library was compiled (binding self-check) */
+size_t ftl_sizeof_config(void);
+size_t ftl_sizeof_scenarios(void);
+size_t ftl_sizeof_outputs(void);
+size_t ftl_sizeof_scen_params(void);
+
+
 /* step()/reset() outputs = (obs, reward, done, info) of ENV:945 for n envs, device arrays */
 typedef struct ftl_outputs {
     float*   obs_num;    /* [n][10]            numerical_features (ENV:1793-1802) */
