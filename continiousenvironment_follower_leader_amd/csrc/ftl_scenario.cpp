@@ -17,7 +17,6 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
-#include <queue>
 #include <thread>
 #include <vector>
 
@@ -126,19 +125,24 @@ bool plan_route(const Grid& g, int sx, int sy, int gx, int gy, int max_iterat, s
     if (g.obst[(size_t)gx * g.cols + gy] || g.obst[(size_t)sx * g.cols + sy]) return false;
     const int N = g.rows * g.cols;
     const double INF = 1e300;
-    std::vector<double> h((size_t)N, INF);
-    std::vector<int> parent((size_t)N, -1);
-    std::vector<uint8_t> closed((size_t)N, 0);
+    // per-thread scratch (the generator is called for thousands of scenarios per thread)
+    static thread_local std::vector<double> h;
+    static thread_local std::vector<int> parent;
+    static thread_local std::vector<uint8_t> closed;
+    h.assign((size_t)N, INF); parent.assign((size_t)N, -1); closed.assign((size_t)N, 0);
     struct Item { double k; uint32_t seq; int id; };
     struct Cmp { bool operator()(const Item& a, const Item& b) const { return a.k > b.k || (a.k == b.k && a.seq > b.seq); } };
-    std::priority_queue<Item, std::vector<Item>, Cmp> open;
+    static thread_local std::vector<Item> open;           // binary heap (std::push_heap / pop_heap), smallest (k, seq) on top
+    open.clear();
+    const Cmp cmp;
     uint32_t seq = 0;
     const int goal = gx * g.cols + gy, start = sx * g.cols + sy;
     h[(size_t)goal] = 0.0;
-    open.push(Item{0.0, seq++, goal});
+    open.push_back(Item{0.0, seq++, goal});
     const double SQ2 = sqrt(2.0);
     while (!open.empty()) {
-        Item it = open.top(); open.pop();
+        std::pop_heap(open.begin(), open.end(), cmp);
+        Item it = open.back(); open.pop_back();
         if (closed[(size_t)it.id] || it.k != h[(size_t)it.id]) continue;
         closed[(size_t)it.id] = 1;
         if (it.id == start) break;
@@ -151,7 +155,7 @@ bool plan_route(const Grid& g, int sx, int sy, int gx, int gy, int max_iterat, s
                 const int nid = nx * g.cols + ny;
                 if (g.obst[(size_t)nid] || closed[(size_t)nid]) continue;
                 const double hn = it.k + ((i && j) ? SQ2 : 1.0);
-                if (hn < h[(size_t)nid]) { h[(size_t)nid] = hn; parent[(size_t)nid] = it.id; open.push(Item{hn, seq++, nid}); }
+                if (hn < h[(size_t)nid]) { h[(size_t)nid] = hn; parent[(size_t)nid] = it.id; open.push_back(Item{hn, seq++, nid}); std::push_heap(open.begin(), open.end(), cmp); }
             }
     }
     if (!closed[(size_t)start]) return false;                 // unreachable goal: the reference would never return
