@@ -2,10 +2,13 @@
 ``reset`` / ``step`` signatures, observation dict keys / shapes / dtypes, ``info`` strings and spaces as the
 reference's ``class Game(gym.Env)`` (follow_the_leader_continuous_env.py:44-105, 429-543, 908-945, 1789-1824).
 
-reset-time scenario generation (rejection-sampled rocks, D*/A* route; ENV:545-677, 1493-1630) is the next row of the
-scope table and is NOT re-implemented here: ``reset()`` takes its scenario from a pool of
-post-reset scenarios (``scenarios=`` kwarg; e.g. tests/golden/pool_B.npz captured from the reference), and ``seed(v)``
-selects the pool entry ``v mod P``."""
+``reset()`` builds its scenario with the host-side generator (scenario.py / ``ftl_generate_scenarios``): after
+``seed(v)`` the first ``reset()`` yields the scenario of the reference's ``game.seed(v); game.reset()`` (rocks, robots,
+route -- up to the choice among equal-cost routes).  Differences: later resets without a new ``seed()`` draw
+from a fresh stream keyed on (v, reset number) instead of continuing the global Mersenne twister, and a scenario the
+reference would start with a broken route (finish point inside an inflated obstacle, ``found_target_point`` False) is
+re-drawn.  With ``scenarios=`` (a ``ScenarioPool`` or an .npz captured from the reference) ``seed(v)`` selects pool entry
+``v mod P`` instead."""
 from collections import OrderedDict
 
 import numpy as np
@@ -69,27 +72,42 @@ class Game:
         self._device = device
         self._vec = None
         self._seed = 0
+        self._resets_since_seed = 0
         self.simulation_number = 0
         self.done = False
 
     # ------------------------------------------------------------------ gym API
     def seed(self, seed_value):                                    # ENV:429-432
         self._seed = int(seed_value)
+        self._resets_since_seed = 0
 
     def _ensure(self):
         if self._vec is None:
-            if self._scenarios is None:
-                raise ValueError("Game(scenarios=...) is required: reset-time scenario generation is outside the "
-                                 "accelerated path (see the module docstring)")
             self._vec = VecGame(1, device=self._device, config=self.cfg)
             pool = self._scenarios
             if isinstance(pool, str):
                 pool = ScenarioPool.from_npz(self.cfg, pool, self._device)
-            self._vec.load_scenarios(pool)
+            if pool is not None:
+                self._vec.load_scenarios(pool)
             self._act = torch.zeros(1, 2, dtype=torch.float64, device=self._device)
+
+    def _generated_pool(self):
+        """One-entry pool for this reset: python seed v for the first reset after seed(v), a derived seed afterwards;
+        unusable scenarios (see the module docstring) are re-drawn."""
+        k = self._resets_since_seed
+        for attempt in range(64):
+            s = self._seed if (k == 0 and attempt == 0) else int(abi.mix64((self._seed << 20) ^ (k << 8) ^ attempt) >> 2)
+            try:
+                return ScenarioPool.generate(self.cfg, [s], self._device, n_threads=1)
+            except ValueError:
+                continue
+        raise RuntimeError("no usable scenario in 64 draws")
 
     def reset(self):                                               # ENV:434-543
         self._ensure()
+        if self._scenarios is None:
+            self._vec.load_scenarios(self._generated_pool())
+        self._resets_since_seed += 1
         idx = torch.tensor([self._seed % self._vec.pool.n], dtype=torch.int32)
         self._vec.reset(idx)
         self.simulation_number += 1

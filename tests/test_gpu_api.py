@@ -67,6 +67,31 @@ def test_game_facade_replays_a_reference_episode():
     g.close()
 
 
+@pytest.mark.parametrize("name", ["B_s3_chase_noisy", "E_s5_random", "D_s2_chase"])
+def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
+    """The whole drop-in: Game(**kwargs); seed(s); reset(); step(a)... reproduces the reference's episode with the
+    scenario built by the host-side generator from the python seed alone (nothing captured from the reference)."""
+    from continiousenvironment_follower_leader_amd.game import Game
+    z, meta = load_episode(name)
+    kw = dict(config_for(meta).kwargs)
+    for k in ("traj_cap", "corr_cap", "route_cap", "init_traj_cap", "n_static", "rng_seed", "env_id_base"):
+        kw.pop(k, None)
+    g = Game(route_cap=256, **kw)
+    g.seed(meta["seed"])
+    obs = g.reset()
+    assert close(obs["numerical_features"], z["reset:num"]).all()
+    for ln in meta["laser_names"]:
+        assert close(obs[ln], z["reset:laser:" + ln]).all()
+    for t in range(min(40, len(z["actions"]))):
+        obs, rew, done, info = g.step(tuple(z["actions"][t]))
+        assert close(obs["numerical_features"], z["obs:num"][t]).all(), (t, obs["numerical_features"] - z["obs:num"][t])
+        for ln in meta["laser_names"]:
+            assert close(obs[ln], z["obs:laser:" + ln][t]).all()
+        assert obs["leader_target_point"] == tuple(z["obs:target"][t])
+        assert abs(rew - z["reward"][t]) <= 1e-5 and done == bool(z["done"][t])
+    g.close()
+
+
 def test_auto_reset_equals_explicit_reset():
     """An env that finishes under FTL_STEP_AUTO_RESET must continue exactly like a fresh env reset to the next scenario."""
     n = 96
