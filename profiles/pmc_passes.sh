@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+B="python3 bench.py --steps 20 --warmup 100 --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH --output-format csv -d gpurun_out/pmc1 -- $B > gpurun_out/pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d gpurun_out/pmc2 -- $B > gpurun_out/pmc2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 --output-format csv -d gpurun_out/pmc3 -- $B > gpurun_out/pmc3.log 2>&1
