@@ -98,6 +98,8 @@ class VecGame:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.FtlError("VecGame needs a ROCm device (got %s): there is no CPU path" % self.device)
+        if not torch.cuda.is_available():
+            raise _lib.FtlError("no ROCm device is visible: the batched env runs on the GPU only (there is no CPU path)")
         self.lib = _lib.load()
         h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()

@@ -82,7 +82,12 @@ def test_spaces():
     assert act.low[0] == -0.25
 
 
-def test_game_facade_needs_scenarios():
+def test_game_facade_fails_loudly_without_a_gpu():
+    """No CPU fallback: on a box without a ROCm device reset() raises instead of computing anything on the host."""
+    import torch
+    from continiousenvironment_follower_leader_amd._lib import FtlError
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
     g = Game(bear_number=1)
-    with pytest.raises(ValueError):
+    with pytest.raises(FtlError):
         g.reset()
