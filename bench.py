@@ -109,8 +109,9 @@ def main():
     pool_path = os.path.join(GOLDEN, "pool_B.npz")
     z = np.load(pool_path)
     meta = json.loads(str(z["meta"]))
-    cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=int(z["route_len"].max()))
     n = a.envs_per_gpu
+    # env_id_base: global env ids (keys of the per-env random streams of row a12) stay distinct across ranks
+    cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=int(z["route_len"].max()), env_id_base=rank * n)
     env = VecGame(n, device=device, config=cfg)
     pool = ScenarioPool.from_npz(cfg, pool_path, device)
     env.load_scenarios(pool)

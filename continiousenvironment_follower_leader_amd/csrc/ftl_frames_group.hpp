@@ -713,34 +713,41 @@ __device__ __forceinline__ double g_hist_dist(const FtlDevParams& P, int env, in
 }
 // numpy pairwise sum of the m-1 consecutive distances of hist[lo..hi) without staging them (a[i] = dist(lo+i, lo+i+1));
 // T is the array dtype (float when no seeded float64 point is left).  n <= 128 * 4 (validated on the host).
-template <typename T>
-__device__ __forceinline__ T g_pw128(const FtlDevParams& P, int env, int first, int n, bool f64) {
-    if (n < 8) { T r = (T)0; for (int i = 0; i < n; i++) r += (T)g_hist_dist(P, env, first + i, f64); return r; }
-    T r0 = (T)g_hist_dist(P, env, first, f64), r1 = (T)g_hist_dist(P, env, first + 1, f64), r2 = (T)g_hist_dist(P, env, first + 2, f64),
-      r3 = (T)g_hist_dist(P, env, first + 3, f64), r4 = (T)g_hist_dist(P, env, first + 4, f64), r5 = (T)g_hist_dist(P, env, first + 5, f64),
-      r6 = (T)g_hist_dist(P, env, first + 6, f64), r7 = (T)g_hist_dist(P, env, first + 7, f64);
+// The eight interleaved accumulators of numpy's unrolled loop are spread over the G lanes of the env's group (8/G each)
+// and combined in numpy's order ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) with width-G shuffles -- IEEE addition commutes, so
+// every lane ends with the same bits as the sequential form.  Must be called by all G lanes of the group.
+template <typename T, int G>
+__device__ __forceinline__ T g_pw128(const FtlDevParams& P, int env, int r, int first, int n, bool f64) {
+    if (n < 8) { T s = (T)0; for (int i = 0; i < n; i++) s += (T)g_hist_dist(P, env, first + i, f64); return s; }
+    constexpr int APL = 8 / G;                     // accumulators per lane
+    T acc[APL];
+#pragma unroll
+    for (int a = 0; a < APL; a++) acc[a] = (T)g_hist_dist(P, env, first + r * APL + a, f64);
     int i;
     for (i = 8; i < n - (n % 8); i += 8) {
-        r0 += (T)g_hist_dist(P, env, first + i, f64); r1 += (T)g_hist_dist(P, env, first + i + 1, f64);
-        r2 += (T)g_hist_dist(P, env, first + i + 2, f64); r3 += (T)g_hist_dist(P, env, first + i + 3, f64);
-        r4 += (T)g_hist_dist(P, env, first + i + 4, f64); r5 += (T)g_hist_dist(P, env, first + i + 5, f64);
-        r6 += (T)g_hist_dist(P, env, first + i + 6, f64); r7 += (T)g_hist_dist(P, env, first + i + 7, f64);
+#pragma unroll
+        for (int a = 0; a < APL; a++) acc[a] += (T)g_hist_dist(P, env, first + i + r * APL + a, f64);
     }
-    T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    T res = acc[0];
+    if constexpr (APL == 2) res = acc[0] + acc[1];                               // r_{2k} + r_{2k+1}
+    else res = res + __shfl_xor(res, 1, G);
+    res = res + __shfl_xor(res, APL == 2 ? 1 : 2, G);                             // (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)
+    res = res + __shfl_xor(res, APL == 2 ? 2 : 4, G);
     for (; i < n; i++) res += (T)g_hist_dist(P, env, first + i, f64);
     return res;
 }
-template <typename T, int DEPTH>
-__device__ __forceinline__ T g_pw(const FtlDevParams& P, int env, int first, int n, bool f64) {
-    if (n <= 128) return g_pw128<T>(P, env, first, n, f64);
-    if constexpr (DEPTH == 0) return g_pw128<T>(P, env, first, n, f64);
-    else { int n2 = n / 2; n2 -= n2 % 8; return g_pw<T, DEPTH - 1>(P, env, first, n2, f64) + g_pw<T, DEPTH - 1>(P, env, first + n2, n - n2, f64); }
+template <typename T, int DEPTH, int G>
+__device__ __forceinline__ T g_pw(const FtlDevParams& P, int env, int r, int first, int n, bool f64) {
+    if (n <= 128) return g_pw128<T, G>(P, env, r, first, n, f64);
+    if constexpr (DEPTH == 0) return g_pw128<T, G>(P, env, r, first, n, f64);
+    else { int n2 = n / 2; n2 -= n2 % 8; return g_pw<T, DEPTH - 1, G>(P, env, r, first, n2, f64) + g_pw<T, DEPTH - 1, G>(P, env, r, first + n2, n - n2, f64); }
 }
+template <int G>
 __device__ __forceinline__ double g_path_length(const FtlDevParams& P, const GCtx& E, int lo, int hi) {
     int m = hi - lo;
     if (m < 2) return 0.0;
-    if (lo < E.seed_end) return g_pw<double, 2>(P, E.env, lo, m - 1, true);
-    return (double)g_pw<float, 2>(P, E.env, lo, m - 1, false);
+    if (lo < E.seed_end) return g_pw<double, 2, G>(P, E.env, E.r, lo, m - 1, true);
+    return (double)g_pw<float, 2, G>(P, E.env, E.r, lo, m - 1, false);
 }
 __device__ __forceinline__ void g_border_pair(const FtlDevParams& P, const GCtx& E, int i1, int i0, int ia, int at, bool write) {
     const double* p1 = hist_slot(P, E.env, i1); const double* p0 = hist_slot(P, E.env, i0); const double* a = hist_slot(P, E.env, ia);
@@ -840,11 +847,11 @@ __device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
         __syncthreads();
         // ---- phase B: trim to corridor_length, append the border pair(s) ------------------------------------------------
         if (save) {
-            double path = g_path_length(P, E, E.corr_lo, E.corr_hi);          // sensors.py:288-297
+            double path = g_path_length<G>(P, E, E.corr_lo, E.corr_hi);          // sensors.py:288-297
             while (path > c.corridor_length) {
                 if (first) E.error |= FTL_ERR_TRACKER_SEED;                   // reference: popleft on the still-empty corridor deque
                 E.corr_lo += 1;
-                path = g_path_length(P, E, E.corr_lo, E.corr_hi);
+                path = g_path_length<G>(P, E, E.corr_lo, E.corr_hi);
             }
             int m = E.corr_hi - E.corr_lo;
             if (m > 1) {                                                      // sensors.py:299-317
