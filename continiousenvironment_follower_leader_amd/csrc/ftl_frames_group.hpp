@@ -736,18 +736,39 @@ __device__ __forceinline__ T g_pw128(const FtlDevParams& P, int env, int r, int 
     for (; i < n; i++) res += (T)g_hist_dist(P, env, first + i, f64);
     return res;
 }
-template <typename T, int DEPTH, int G>
+// numpy's pairwise_sum recursion above its 128-element leaf, for n <= 512 (two levels; validated on the host), written as
+// loops around ONE inlined copy of the leaf (the recursive template form expanded it 7 times per dtype -- instruction cache)
+template <typename T, int G>
 __device__ __forceinline__ T g_pw(const FtlDevParams& P, int env, int r, int first, int n, bool f64) {
-    if (n <= 128) return g_pw128<T, G>(P, env, r, first, n, f64);
-    if constexpr (DEPTH == 0) return g_pw128<T, G>(P, env, r, first, n, f64);
-    else { int n2 = n / 2; n2 -= n2 % 8; return g_pw<T, DEPTH - 1, G>(P, env, r, first, n2, f64) + g_pw<T, DEPTH - 1, G>(P, env, r, first + n2, n - n2, f64); }
+    int hn[2] = {n, 0};
+    if (n > 128) { int n2 = n / 2; n2 -= n2 % 8; hn[0] = n2; hn[1] = n - n2; }
+    T total = (T)0;
+    int hf = first;
+#pragma nounroll
+    for (int h = 0; h < 2; h++) {
+        if (hn[h] == 0) break;
+        int qn[2] = {hn[h], 0};
+        if (hn[h] > 128) { int n2 = hn[h] / 2; n2 -= n2 % 8; qn[0] = n2; qn[1] = hn[h] - n2; }
+        T hs = (T)0;
+        int qf = hf;
+#pragma nounroll
+        for (int q = 0; q < 2; q++) {
+            if (qn[q] == 0) break;
+            const T v = g_pw128<T, G>(P, env, r, qf, qn[q], f64);
+            hs = q == 0 ? v : hs + v;
+            qf += qn[q];
+        }
+        total = h == 0 ? hs : total + hs;
+        hf += hn[h];
+    }
+    return total;
 }
 template <int G>
 __device__ __forceinline__ double g_path_length(const FtlDevParams& P, const GCtx& E, int lo, int hi) {
     int m = hi - lo;
     if (m < 2) return 0.0;
-    if (lo < E.seed_end) return g_pw<double, 2, G>(P, E.env, E.r, lo, m - 1, true);
-    return (double)g_pw<float, 2, G>(P, E.env, E.r, lo, m - 1, false);
+    if (lo < E.seed_end) return g_pw<double, G>(P, E.env, E.r, lo, m - 1, true);
+    return (double)g_pw<float, G>(P, E.env, E.r, lo, m - 1, false);
 }
 __device__ __forceinline__ void g_border_pair(const FtlDevParams& P, const GCtx& E, int i1, int i0, int ia, int at, bool write) {
     const double* p1 = hist_slot(P, E.env, i1); const double* p0 = hist_slot(P, E.env, i0); const double* a = hist_slot(P, E.env, ia);
