@@ -125,10 +125,10 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     }
     h->state_bytes = align_up(cur, 256);
     {   // corridor ring (f32x4) + near rects (int4 + u32) + corridor refs (u32) + green caps (f32x4 + u32) + counters
-        // + ray ends (double2) + per-(ray, snapshot) minima (u64 x 8)
+        // + ray ends (double2) + per-(ray, snapshot) minima (u64 x HM) + miss readings (f64)
         const size_t rects = (size_t)cfg->n_static + hmax + (size_t)hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
         P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + rects * 20 + (size_t)2 * cfg->corr_cap * 4 + (size_t)2 * hmax * 20 + 64
-                           + (size_t)rays * 16 + (size_t)rays * 8 * 8);
+                           + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : 8) * 8 + (size_t)rays * 8);
     }
     if (P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
     *out = h;

@@ -390,6 +390,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     const int n_u32 = (cap_rs + cap_rd) + cap_cr + cap_gr + 4;                   // words since the last 16-byte aligned array
     double2* s_ray = reinterpret_cast<double2*>(s_rmask + ((n_u32 + 3) & ~3));     // 16-byte aligned [total_rays]
     unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [total_rays][HM]
+    double* s_miss = reinterpret_cast<double*>(s_best + (size_t)P.total_rays * HM);                     // [total_rays] |ray end - origin|
     const unsigned long long kInfBits = 0x7fefffffffffffffull;                                       // DBL_MAX: "no hit"
 
     // Round trip 1: everything that is addressed by the env index alone is requested at once -- the scalars, every ring slot
@@ -490,21 +491,27 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             }
         }
         FTL_RTIC(1);
-        // ---- phase 2: ray ends of every sensor of this group + accumulators ------------------------------------------------
+        // ---- phase 2: ray ends + accumulators; the rays of ALL sensors of this group share one index space (a sensor
+        // of 12 rays alone would leave 52 lanes idle through the f64 sin/cos)
         {
-            int base = 0;
-            for (int k = 0; k < c.n_lasers; k++) {
-                if (c.lasers[k].after_tracker != which) continue;
-                const int N = c.lasers[k].count;
-                const double len = c.lasers[k].length, aoff = c.lasers[k].angle_offset, period = 360.0 / (double)N;
-                for (int i = lane; i < N; i += FTL_WAVE) {
-                    double s, co;
-                    sincos_bounded(((fdir + aoff) + i * period) * kDeg2Rad, s, co);
-                    s_ray[base + i] = make_double2((double)cx + co * len, (double)cy + s * len);
-#pragma unroll
-                    for (int j = 0; j < HM; j++) s_best[(base + i) * HM + j] = kInfBits;
+            int n_rays = 0;
+            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) n_rays += c.lasers[k].count;
+            for (int g = lane; g < n_rays; g += FTL_WAVE) {
+                int i = g; double len = 0, aoff = 0, period = 0; bool found = false;
+                for (int k = 0; k < c.n_lasers; k++) {
+                    if (c.lasers[k].after_tracker != which) continue;
+                    const int N = c.lasers[k].count;
+                    if (!found && i < N) { found = true; len = c.lasers[k].length; aoff = c.lasers[k].angle_offset; period = 360.0 / (double)N; }
+                    if (!found) i -= N;
                 }
-                base += N;
+                double s, co;
+                sincos_bounded(((fdir + aoff) + i * period) * kDeg2Rad, s, co);
+                const double ex = (double)cx + co * len, ey = (double)cy + s * len;
+                s_ray[g] = make_double2(ex, ey);
+                const double qx0 = ex - (double)cx, qy0 = ey - (double)cy;
+                s_miss[g] = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));            // np.linalg.norm(end - position), sensors.py:925-930
+#pragma unroll
+                for (int j = 0; j < HM; j++) s_best[g * HM + j] = kInfBits;
             }
         }
         __syncthreads();
@@ -621,32 +628,39 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 }
             }
             if (any_pad) __syncthreads();
-            int base = 0;
-            for (int k = 0; k < c.n_lasers; k++) {
-                if (c.lasers[k].after_tracker != which) continue;
-                const int N = c.lasers[k].count, H = c.lasers[k].history, ooff = c.lasers[k].out_offset;
-                const bool pad = c.lasers[k].pad_sectors != 0;
-                const int Wd = pad ? 4 * N : N;
-                const float flen = (float)c.lasers[k].length;           // python number / float32 array -> float32 division
-                const double lis = (double)N / 4.0;                     // lasers_in_sector (sensors.py:938)
-                for (int i = lane; i < N; i += FTL_WAVE) {
-                    const double2 e = s_ray[base + i];
-                    double qx0 = e.x - (double)cx, qy0 = e.y - (double)cy;
-                    const double miss = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));
-                    int col = i;
-                    if (pad) { const double di = (double)i; col = (di < lis ? 0 : (di < 2 * lis ? 1 : (di < 3 * lis ? 2 : 3))) * N + i; }
-#pragma unroll
-                    for (int a2 = 0; a2 < HM; a2++) {
-                        if (a2 < H) {
-                            unsigned long long b = s_best[(base + i) * HM + a2];
-                            double v = (a2 < nsnap && b != kInfBits) ? sqrt(__longlong_as_double((long long)b)) : miss;
-                            const float vf = (float)v;
-                            out_base[ooff + (H - 1 - a2) * Wd + col] = vf;
-                            if (pol) pol[(H - 1 - a2) * P.pol_width + P.pol_off[k] + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
+            // one (ray, age) pair per lane over all sensors of the group: pair p of sensor k = age * N_k + ray
+            int n_pairs = 0;
+            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) n_pairs += c.lasers[k].count * c.lasers[k].history;
+            for (int p = lane; p < n_pairs; p += FTL_WAVE) {
+                int q = p, N = 1, H = 1, ooff = 0, rb = 0, poff = 0; bool pad = false, found = false; float flen = 1.0f;
+                {
+                    int rbase = 0;
+                    for (int k = 0; k < c.n_lasers; k++) {
+                        if (c.lasers[k].after_tracker != which) continue;
+                        const int np = c.lasers[k].count * c.lasers[k].history;
+                        if (!found && q < np) {
+                            found = true; N = c.lasers[k].count; H = c.lasers[k].history; ooff = c.lasers[k].out_offset; rb = rbase;
+                            pad = c.lasers[k].pad_sectors != 0; flen = (float)c.lasers[k].length; poff = P.pol_off[k];   // python number / float32 array -> float32 division
                         }
+                        if (!found) q -= np;
+                        rbase += c.lasers[k].count;
                     }
                 }
-                base += N;
+                int a2 = 0;
+#pragma unroll
+                for (int j = 1; j < HM; j++) a2 += (q >= j * N) ? 1 : 0;         // q / N without an integer division (a2 < H <= HM)
+                const int i = q - a2 * N;
+                const int Wd = pad ? 4 * N : N;
+                int col = i;
+                if (pad) {
+                    const double lis = (double)N / 4.0, di = (double)i;         // lasers_in_sector (sensors.py:938)
+                    col = (di < lis ? 0 : (di < 2 * lis ? 1 : (di < 3 * lis ? 2 : 3))) * N + i;
+                }
+                const unsigned long long bb = s_best[(rb + i) * HM + a2];
+                const double v = (a2 < nsnap && bb != kInfBits) ? sqrt(__longlong_as_double((long long)bb)) : s_miss[rb + i];
+                const float vf = (float)v;
+                out_base[ooff + (H - 1 - a2) * Wd + col] = vf;
+                if (pol) pol[(H - 1 - a2) * P.pol_width + poff + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
             }
         }
         FTL_RTIC(6);
