@@ -401,11 +401,17 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     const int4* srp = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)env * hmax * nrect_dyn;
     const int swv = lane < hmax * 4 ? swp[lane] : 0;
     const int4 dynq = lane < hmax * nrect_dyn ? srp[lane] : make_int4(0, 0, 0, 0);
-    const int scen = ei[FTL_EI_SCEN], snap_count = ei[FTL_EI_SNAP_COUNT], scan_ok = ei[FTL_EI_SCAN_OK];
-    const int newest = (ei[FTL_EI_SNAP_HEAD] == 0 ? hmax : ei[FTL_EI_SNAP_HEAD]) - 1;   // ring slot of the newest snapshot
+    // per-env scalars come through VECTOR loads (one word per lane) and are made wave-uniform with readlane: streaming
+    // them through the scalar cache (s_load) costs several microseconds per miss under this kernel's load
     const size_t fo = (size_t)env * P.R + 1;            // follower
-    const float cx = P.rb_pos[2 * fo], cy = P.rb_pos[2 * fo + 1];
-    const double fdir = P.rb_dbl[fo * FTL_RD_COUNT + FTL_RD_DIRECTION];
+    const int eiv = lane < FTL_EI_COUNT ? ei[lane] : 0;
+    const int fpv = lane < 2 ? __float_as_int(P.rb_pos[2 * fo + lane]) : 0;
+    const int fdv = lane < 2 ? reinterpret_cast<const int*>(P.rb_dbl + fo * FTL_RD_COUNT + FTL_RD_DIRECTION)[lane] : 0;
+    const int scen = __builtin_amdgcn_readlane(eiv, FTL_EI_SCEN), snap_count = __builtin_amdgcn_readlane(eiv, FTL_EI_SNAP_COUNT);
+    const int scan_ok = __builtin_amdgcn_readlane(eiv, FTL_EI_SCAN_OK), snap_head = __builtin_amdgcn_readlane(eiv, FTL_EI_SNAP_HEAD);
+    const int newest = (snap_head == 0 ? hmax : snap_head) - 1;   // ring slot of the newest snapshot
+    const float cx = __int_as_float(__builtin_amdgcn_readlane(fpv, 0)), cy = __int_as_float(__builtin_amdgcn_readlane(fpv, 1));
+    const double fdir = __hiloint2double(__builtin_amdgcn_readlane(fdv, 1), __builtin_amdgcn_readlane(fdv, 0));
     float* out_base = C.out.lasers + (size_t)env * P.lasers_len;
     const int nsnap = snap_count < hmax ? snap_count : hmax;       // valid snapshots, newest = snap_count-1
     const unsigned all_snaps = (1u << nsnap) - 1u;                  // bit a = age a (nsnap <= 8)
@@ -434,6 +440,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 umin = min(umin, win_lo[a]); umax = max(umax, win_hi[a]);
             }
         }
+        FTL_RTIC(7);
         __syncthreads();
         if (lane < SEG_CLASSES) s_cnt[lane] = 0;
         for (int p = umin + lane; p < umax; p += FTL_WAVE) {
@@ -515,6 +522,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             }
         }
         __syncthreads();
+        FTL_RTIC(2);
 
         // ---- phase 3: (sensor, segment) pairs x candidate rays -----------------------------------------------------------------
         {

@@ -25,9 +25,9 @@ for phase, steps in (("steps 0-30", 30), ("steps 30-150", 120), ("steps 150-250"
     print(phase, "cycles share:", " ".join("%s=%.3f" % (cn[i], cy[i] / tot) for i in range(12)), "cycles/wave-step=%.0f" % (tot / (steps * n / 16)))
     rc = v[32:48]
     if sum(rc[:8]):
-        rn = ["stage corridor", "phase1 table", "phase2 ray ends", "phase3 decode", "phase3 arcs", "phase3 ray tests", "phase4 rows"]
-        rt = sum(rc[:7])
-        print(phase, "RAYS cycles share:", " ".join("%s=%.3f" % (rn[i], rc[i] / rt) for i in range(7)), "cycles/env-step=%.0f" % (rt / (steps * n)),
+        rn = ["stage corridor (2nd trip)", "phase1 table", "phase2 ray ends", "phase3 decode", "phase3 arcs", "phase3 ray tests", "phase4 rows", "setup (1st trip)"]
+        rt = sum(rc[:8])
+        print(phase, "RAYS cycles share:", " ".join("%s=%.3f" % (rn[i], rc[i] / rt) for i in range(8)), "cycles/env-step=%.0f" % (rt / (steps * n)),
               "chunks/env-step=%.2f max-cnt/chunk=%.2f sum-cnt/chunk=%.1f items/chunk=%.1f" % (rc[8] / (steps * n), rc[9] / max(rc[8], 1), rc[10] / max(rc[8], 1), rc[11] / max(rc[8], 1)))
     print(phase, " ".join("%s=%.4f" % (names[i], v[i] / fr) for i in range(1, 16)), "waves/frame-wave: green %.3f full %.3f" % (v[8] / (fr / 16), v[9] / (fr / 16)))
 wh = (C.c_uint * 128)()
