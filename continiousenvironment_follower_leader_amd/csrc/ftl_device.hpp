@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 FTL_RTIC(4);
 #ifdef FTL_PROFILE_RAYS
                 if (threadIdx.x == 0) { s_rcyc[8] += 1; }
-                { int mc = cnt; for (int o = 32; o >= 1; o >>= 1) mc = max(mc, __shfl_xor(mc, o)); int ni = __popcll(__ballot(m >= 0)); int sc = cnt; for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o); if (threadIdx.x == 0) { s_rcyc[9] += mc; s_rcyc[10] += sc; s_rcyc[11] += ni; } }
+                { int mc = cnt; for (int o = 32; o >= 1; o >>= 1) mc = max(mc, __shfl_xor(mc, o)); int ni = __popcll(__ballot(m >= 0)); int sc = cnt; for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o); int n4 = __popcll(__ballot(cnt > 4)); if (threadIdx.x == 0) { s_rcyc[9] += mc; s_rcyc[10] += sc; s_rcyc[11] += ni; s_rcyc[12] += (mc <= 2); s_rcyc[13] += (mc > 2 && mc <= 4); s_rcyc[14] += (mc > 4 && mc <= 8); s_rcyc[15] += (mc > 8); } (void)n4; }
 #endif
                 for (int t = 0; t < cnt; t++) {
                     int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);

@@ -28,7 +28,8 @@ for phase, steps in (("steps 0-30", 30), ("steps 30-150", 120), ("steps 150-250"
         rn = ["stage corridor (2nd trip)", "phase1 table", "phase2 ray ends", "phase3 decode", "phase3 arcs", "phase3 ray tests", "phase4 rows", "setup (1st trip)"]
         rt = sum(rc[:8])
         print(phase, "RAYS cycles share:", " ".join("%s=%.3f" % (rn[i], rc[i] / rt) for i in range(8)), "cycles/env-step=%.0f" % (rt / (steps * n)),
-              "chunks/env-step=%.2f max-cnt/chunk=%.2f sum-cnt/chunk=%.1f items/chunk=%.1f" % (rc[8] / (steps * n), rc[9] / max(rc[8], 1), rc[10] / max(rc[8], 1), rc[11] / max(rc[8], 1)))
+              "chunks/env-step=%.2f max-cnt/chunk=%.2f sum-cnt/chunk=%.1f items/chunk=%.1f" % (rc[8] / (steps * n), rc[9] / max(rc[8], 1), rc[10] / max(rc[8], 1), rc[11] / max(rc[8], 1)),
+              "chunks by max cnt: <=2 %.3f  3-4 %.3f  5-8 %.3f  >8 %.3f" % tuple(rc[12 + j] / max(rc[8], 1) for j in range(4)))
     print(phase, " ".join("%s=%.4f" % (names[i], v[i] / fr) for i in range(1, 16)), "waves/frame-wave: green %.3f full %.3f" % (v[8] / (fr / 16), v[9] / (fr / 16)))
 wh = (C.c_uint * 128)()
 env.lib.ftl_debug_whist(wh, 0)
