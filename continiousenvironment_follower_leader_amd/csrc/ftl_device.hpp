@@ -441,6 +441,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             }
         }
         FTL_RTIC(7);
+#if defined(FTL_RAYS_STOP) && FTL_RAYS_STOP == 0      // diagnostic builds (profiles/tools/rays_phase_valu.sh): stop after a phase
+        continue;
+#endif
         __syncthreads();
         if (lane < SEG_CLASSES) s_cnt[lane] = 0;
         for (int p = umin + lane; p < umax; p += FTL_WAVE) {
@@ -449,6 +452,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         }
         __syncthreads();
         FTL_RTIC(0);
+#if defined(FTL_RAYS_STOP) && FTL_RAYS_STOP == 1
+        continue;
+#endif
 
         // ---- phase 1: culled, compacted segment table; sources flattened: statics | snapshot rects | corridor points | caps
         const float reach = lmax + 2.0f;
@@ -498,6 +504,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             }
         }
         FTL_RTIC(1);
+#if defined(FTL_RAYS_STOP) && FTL_RAYS_STOP == 2
+        continue;
+#endif
         // ---- phase 2: ray ends + accumulators; the rays of ALL sensors of this group share one index space (a sensor
         // of 12 rays alone would leave 52 lanes idle through the f64 sin/cos)
         {
@@ -523,6 +532,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         }
         __syncthreads();
         FTL_RTIC(2);
+#if defined(FTL_RAYS_STOP) && FTL_RAYS_STOP == 3
+        continue;
+#endif
 
         // ---- phase 3: (sensor, segment) pairs x candidate rays -----------------------------------------------------------------
         {
@@ -618,6 +630,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             }
         }
         FTL_RTIC(5);
+#if defined(FTL_RAYS_STOP) && FTL_RAYS_STOP == 4
+        continue;
+#endif
         __syncthreads();
         // ---- phase 4: rows, oldest first, newest last (sensors.py:896-901); rows older than the first scan and rays without a
         // hit read |end - origin| (sensors.py:925-930).  pad_sectors (sensors.py:932-953) spreads a row over four N-wide
