@@ -385,7 +385,7 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
 
 template <int G>
 __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near, float4* s_bb, int& tick,
-                                        double& reward, int& i0, int& i1, int& i2) {
+                                        double& reward, int& i0, int& i1, int& i2, const bool first) {
     const ftl_config& c = P.cfg;
     const int r = E.r;
     const bool act = E.valid && r < P.R;
@@ -566,6 +566,20 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         if (h_green && hd2 < eps2_lo) fast = 1;                                         // a green point within epsilon
         else if (h_green && hd2 < dev2_lo && E.clr_g > eps_hi) fast = 2;                // none within epsilon, one within max_dev
         else if (E.clr_g > far_hi) fast = (E.clr_a > eps_hi) ? 3 : (hd2 < eps2_lo ? 4 : 0);   // no green point in reach
+        if (first && fast != 0) {
+            // Refresh ahead of need.  A search is paid by the whole wavefront, whichever env asks for it, so the envs whose
+            // caches would run out somewhere inside this step (the follower moves at most `reach` until its end, the
+            // green window drops at most a few points) all search NOW, in the same frame, instead of in different ones.
+            const float reach = (float)c.frames_per_step * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed)) * 1.001f + 1e-3f;
+            const float hd = sqrtf(hd2);
+            const bool h_stays_green = E.hint >= g_lo + 2 + c.frames_per_step / c.trajectory_saving_period;
+            const float eps_lo = (float)(eps * (1.0 - 1e-5)), dev_lo = (float)(mdev * (1.0 - 1e-5));
+            bool safe;
+            if (fast == 1) safe = h_stays_green && hd + reach < eps_lo;
+            else if (fast == 2) safe = h_stays_green && hd + reach < dev_lo && E.clr_g - reach > eps_hi;
+            else safe = E.clr_g - reach > far_hi && (E.clr_a - reach > eps_hi || hd + reach < eps_lo);
+            if (!safe) fast = 0;
+        }
         FTL_PROF(2, E.valid && r == 0 && fast != 0, 1);
         FTL_PROF(13, E.valid && r == 0 && fast == 0 && h_green && hd2 < dev2_lo, 1);
         FTL_PROF(14, E.valid && r == 0 && fast == 0 && !(h_green && hd2 < dev2_lo) && E.clr_g <= far_hi, 1);
@@ -1002,7 +1016,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
 #else
         for (int f = 0; f < P.cfg.frames_per_step; f++) {                       // ENV:935-936
 #endif
-            g_frame<G>(P, E, L, near, bbl, tick, reward, i0, i1, i2);
+            g_frame<G>(P, E, L, near, bbl, tick, reward, i0, i1, i2, f == 0);
             __syncthreads();          // an appended trajectory point is read by the other lanes of the group next frame
         }
         if (E.valid && E.r == 0) {

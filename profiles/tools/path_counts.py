@@ -10,8 +10,9 @@ z = np.load(GOLDEN + "/pool_B.npz"); meta = json.loads(str(z["meta"]))
 cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=int(z["route_len"].max()))
 n = 65536
 env = VecGame(n, device="cuda:0", config=cfg); pool = ScenarioPool.from_npz(cfg, GOLDEN + "/pool_B.npz", "cuda:0"); env.load_scenarios(pool)
-env.reset((torch.arange(n) % pool.n).to(torch.int32))
-acts = bench.make_actions(cfg, n, 16, 0, torch.device("cuda:0"))
+GROUP = int(os.environ.get("FTL_DIAG_GROUP", "1"))      # >1: make every GROUP consecutive envs identical (no divergence inside a wavefront)
+env.reset(((torch.arange(n) // GROUP) % pool.n).to(torch.int32))
+acts = bench.make_actions(cfg, n // GROUP, 16, 0, torch.device("cuda:0")).repeat_interleave(GROUP, dim=1).contiguous()
 out = (C.c_ulonglong * 48)()
 names = ["frames", "Gc>2", "fast path", "green search", "exact walk", "full search", "blocks scanned (green)", "blocks scanned (full)",
          "waves w/ green search", "waves w/ full search", "search: in eps", "search: in dev", "search: whole-window eps", "fallback: dev-band, eps unproven", "fallback: green bound <= far", "fallback: all bound <= eps"]
