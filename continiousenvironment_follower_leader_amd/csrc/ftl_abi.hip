@@ -252,6 +252,10 @@ int ftl_step(ftl_handle* h, const double* action, const ftl_outputs* out, uint32
 }  // extern "C"
 
 #ifdef FTL_PROFILE_PATHS
+extern "C" int ftl_debug_wave_times(unsigned long long* out) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ftl::g_wave_t), sizeof(unsigned long long) * 2 * 8192) != hipSuccess;
+}
 extern "C" int ftl_debug_whist(unsigned int* out, int clear) {
     hipDeviceSynchronize();
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ftl::g_whist), sizeof(unsigned int) * 128) != hipSuccess) return 1;

@@ -63,6 +63,7 @@ __device__ unsigned long long g_prof[16];
 #define FTL_PROF(slot, cond, n) do { if (cond) atomicAdd(&g_prof[slot], (unsigned long long)(n)); } while (0)
 #endif
 __device__ unsigned long long g_cyc[16];
+__device__ unsigned long long g_wave_t[2 * 8192];    // [wave][start, end] in 100 MHz ticks (s_memrealtime), last launch
 __device__ unsigned int g_whist[2][64];             // wave lifetime histogram (bins of 4096 cycles), [did a reset]
 __shared__ unsigned long long s_cyc[16];           // per-wave accumulators, flushed once at the end of the kernel
 #define FTL_TIC(slot) do { unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) s_cyc[slot] += _t - _tprev; _tprev = _t; } while (0)
@@ -960,6 +961,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     const Limits L = lane_limits(P.cfg, E.r);
 #ifdef FTL_PROFILE_PATHS
     if (threadIdx.x < 16) s_cyc[threadIdx.x] = 0;
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_wave_t[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
 #endif
     FTL_TIC_INIT;
@@ -1045,6 +1047,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
 #ifdef FTL_PROFILE_PATHS
     __syncthreads();
     if (threadIdx.x < 16) atomicAdd(&g_cyc[threadIdx.x], s_cyc[threadIdx.x]);
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_wave_t[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && C.mode != 1) {
         unsigned long long tot = 0; for (int i = 0; i < 11; i++) if (i != 9) tot += s_cyc[i];
         int bin = (int)(tot >> 12); bin = bin > 63 ? 63 : bin;

@@ -39,6 +39,27 @@ for k, nm in enumerate(("no reset", "with reset")):
     tot = wh[k].sum(); cs = np.cumsum(wh[k]) / max(tot, 1)
     print("frame-kernel wave lifetime (last phase), %s: waves=%d mean=%.0f kcyc p10=%d p50=%d p90=%d p99=%d max=%d (x4096 cycles)" % (
         nm, tot, (wh[k] * (np.arange(64) + 0.5) * 4.096).sum() / max(tot, 1), np.searchsorted(cs, 0.1), np.searchsorted(cs, 0.5), np.searchsorted(cs, 0.9), np.searchsorted(cs, 0.99), np.nonzero(wh[k])[0].max() if tot else 0))
+wt = (C.c_ulonglong * (2 * 8192))()
+env.lib.ftl_debug_wave_times(wt)
+wt = np.array(list(wt), dtype=np.int64).reshape(8192, 2)[:n // 16]
+t0 = wt[:, 0].min()
+st, en = (wt[:, 0] - t0) / 100.0, (wt[:, 1] - t0) / 100.0            # microseconds
+print("frame-kernel launch timeline (last step, us): first start 0, start p50=%.1f p90=%.1f last=%.1f | wave duration mean=%.1f p90=%.1f | end p50=%.1f last=%.1f" % (
+    np.percentile(st, 50), np.percentile(st, 90), st.max(), (en - st).mean(), np.percentile(en - st, 90), np.percentile(en, 50), en.max()))
+print("  starts per 10 us:", np.histogram(st, bins=np.arange(0, en.max() + 10, 10))[0].tolist())
+print("  ends   per 10 us:", np.histogram(en, bins=np.arange(0, en.max() + 10, 10))[0].tolist())
 ei = env.state_field("env_int").cpu().numpy()
 from continiousenvironment_follower_leader_amd import abi
 print("traj_len pct", np.percentile(ei[:, abi.EI_TRAJ_LEN], [5, 50, 95]), "green_count pct", np.percentile(ei[:, abi.EI_GREEN_COUNT], [5, 50, 95]), "step_count pct", np.percentile(ei[:, abi.EI_STEP_COUNT], [5, 50, 95]))
+# do wave durations persist from one step to the next (would longest-first launch order help)?
+durs = []
+for k in range(6):
+    env.step(acts[k % 16], auto_reset=True)
+    env.lib.ftl_debug_wave_times(wt_buf := (C.c_ulonglong * (2 * 8192))())
+    a = np.array(list(wt_buf), dtype=np.int64).reshape(8192, 2)[:n // 16]
+    durs.append((a[:, 1] - a[:, 0]) / 100.0)
+durs = np.array(durs)
+print("wave duration correlation between consecutive steps:", [round(float(np.corrcoef(durs[i], durs[i + 1])[0, 1]), 3) for i in range(5)],
+      "lag 2:", round(float(np.corrcoef(durs[0], durs[2])[0, 1]), 3), "lag 4:", round(float(np.corrcoef(durs[0], durs[4])[0, 1]), 3),
+      "std/mean %.3f" % (durs.std() / durs.mean()))
+np.save(os.path.join(os.path.dirname(__file__), "..", "..", "gpurun_out", "wave_durs.npy"), durs)
