@@ -99,7 +99,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         P.cfg.lasers[k].out_offset = off;
         off += cfg->lasers[k].history * cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1);
         hmax = cfg->lasers[k].history > hmax ? cfg->lasers[k].history : hmax;
-        P.rays_k[k] = rays; rays += cfg->lasers[k].count;
+        rays += cfg->lasers[k].count;
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
     // the frame kernel stages at most 48 block boxes per env (registers in flight) and 12 KB per wave

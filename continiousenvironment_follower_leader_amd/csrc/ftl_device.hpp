@@ -28,18 +28,13 @@
 
 #define FTL_WAVE 64
 #define FTL_HMAX 8          // compile-time cap on max_prev_obs (register accumulators)
-#define FTL_DCHUNK 256      // trajectory segment lengths staged per pass of the green-zone walk
-#ifndef FTL_FRAMES_WPE
-#define FTL_FRAMES_WPE 3    // min waves per SIMD the register allocator must leave room for (tuned on MI355X)
-#endif
 #ifndef FTL_RAYS_WPE
 #define FTL_RAYS_WPE 5      // 96 VGPRs; LDS (7 KB per env) caps the CU at ~22 waves anyway
 #endif
 
 struct FtlDevParams {
     ftl_config cfg;
-    int32_t n_envs, R, lasers_len, total_rays, hmax, lds_frames, lds_rays;
-    int32_t rays_k[FTL_MAX_LASERS];   // first global ray id of sensor k
+    int32_t n_envs, R, lasers_len, total_rays, hmax, lds_rays;
     int32_t bb_in_lds;                // the frame kernel stages the trajectory bounding boxes in LDS (they fit)
     int32_t pol_off[FTL_MAX_LASERS], pol_width, pol_h;   // fused sensorPrev output: column offset per sensor, row width, common history
     // per-env state (views into the caller-owned state buffer), all [n_envs][...]
@@ -61,13 +56,6 @@ static constexpr double kDeg2Rad = 3.141592653589793 / 180.0;
 static constexpr double kRad2Deg = 180.0 / 3.141592653589793;
 
 // ---------------------------------------------------------------- cross-lane helpers
-__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ float rl_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
-__device__ __forceinline__ double rl_d(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(__builtin_amdgcn_readlane(hi, lane), __builtin_amdgcn_readlane(lo, lane));
-}
-
 // ---------------------------------------------------------------- scalar math shared by all phases
 // sin & cos of a float64 angle with |x| < ~1e5 rad (every angle on this path is below 15 rad): three-term Cody-Waite
 // reduction by pi/2 carrying the rounding tail, then the fdlibm minimax kernels on [-pi/4, pi/4] (< 1 ulp).  The
