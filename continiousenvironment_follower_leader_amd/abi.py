@@ -25,13 +25,19 @@ FTL_STEP_AUTO_RESET = 1
  EI_STEP_COUNT, EI_FINISH_TIMER, EI_TRAJ_LEN, EI_TRK_COUNTER, EI_CORR_LO, EI_CORR_HI, EI_SEED_END,
  EI_SNAP_COUNT, EI_DYN_INDEX0, EI_DYN_INDEX1, EI_DYN_INDEX2, EI_DYN_INDEX3, EI_ERROR, EI_EPISODES,
  EI_GREEN_COUNT, EI_GREEN_LEN, EI_SCAN_OK, EI_SNAP_HEAD, EI_HINT, EI_GREEN_TINY, EI_RESETS, EI_ACC_CONSUMED,
- EI_HINT_X, EI_HINT_Y, EI_CLR_GREEN, EI_CLR_ALL, EI_PAD, EI_COUNT) = range(36)
+ EI_HINT_X, EI_HINT_Y, EI_CLR_GREEN, EI_CLR_ALL, EI_FPS, EI_COUNT) = range(36)
 ED_ACC_PENALTY, ED_OVERALL_REWARD, ED_SPARE0, ED_SPARE1, ED_BEAR_POINTS = range(5)
 ED_GREEN_W = ED_BEAR_POINTS + 2 * FTL_MAX_BEARS
 ED_CUR_MULT, ED_CUR_ACC, ED_CUM_SPEED = ED_GREEN_W + 1, ED_GREEN_W + 2, ED_GREEN_W + 3
 ED_COUNT = ED_CUM_SPEED + 1
 RD_DIRECTION, RD_SPEED, RD_ROT_SPEED, RD_DES_SPEED, RD_DES_ROT_SPEED, RD_COUNT = range(6)
 RI_X, RI_Y, RI_W, RI_H, RI_ROT_DIR, RI_DES_ROT_DIR, RI_SPARE0, RI_SPARE1, RI_COUNT = range(9)
+
+
+def rand_frames(rng_seed, env_id, resets, step_count, lo, hi):
+    """Twin of ftl_rand_frames (include/ftl.h): the stand-in for np.random.randint(lo, hi) at ENV:405/940."""
+    v = lo + int(uniform01(rng_seed, env_id, resets, step_count | (1 << 40)) * (hi - lo))
+    return v if v < hi else hi - 1
 
 
 class RobotParams(C.Structure):
@@ -67,7 +73,8 @@ class Config(C.Structure):
                 ("lasers", LaserCfg * FTL_MAX_LASERS),
                 ("n_speed_regime", C.c_int32), ("n_acc_regime", C.c_int32),
                 ("speed_key", C.c_int32 * FTL_MAX_REGIME), ("speed_is_range", C.c_int32 * FTL_MAX_REGIME),
-                ("acc_key", C.c_int32 * FTL_MAX_REGIME), ("env_id_base", C.c_int32), ("_pad1", C.c_int32),
+                ("acc_key", C.c_int32 * FTL_MAX_REGIME), ("env_id_base", C.c_int32),
+                ("rand_fps_lo", C.c_int32), ("rand_fps_hi", C.c_int32), ("_pad1", C.c_int32),
                 ("speed_lo", C.c_double * FTL_MAX_REGIME), ("speed_hi", C.c_double * FTL_MAX_REGIME),
                 ("acc_val", C.c_double * FTL_MAX_REGIME), ("rng_seed", C.c_uint64)]
 

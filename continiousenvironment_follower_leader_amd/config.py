@@ -130,8 +130,9 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
     # ---- features of the reference that are outside the accelerated hot path ----------------------
     if manual_control:
         raise NotImplementedError("manual_control (pygame event loop, ENV:913-915) is not part of the batched step path")
-    if random_frames_per_step is not None:
-        raise NotImplementedError("random_frames_per_step draws np.random inside step (ENV:939-940); not supported yet")
+    if random_frames_per_step is not None and frames_per_step is None:
+        raise NotImplementedError("random_frames_per_step without frames_per_step leaves the reference's first step "
+                                  "without a frame count (ENV:399-405)")
     if leader_speed_regime is not None and type(leader_speed_regime) not in (dict, OrderedDict):
         warn("leader_speed_regime должен быть dict или OrderedDict, получено: {}, будет проигнорировано".format(
             type(leader_speed_regime)))  # ENV:387-389
@@ -150,6 +151,11 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
     c.abi_version = abi.FTL_ABI_VERSION
     c.width, c.height = int(game_width), int(game_height)
     c.frames_per_step = int(frames_per_step)
+    if random_frames_per_step is not None:                  # ENV:399-405, 939-940: np.random.randint(lo, hi) per step,
+        warn("Одновременно заданы и random_frames_per_step и frames_per_step, будет использоваться random_frames_per_step")
+        c.rand_fps_lo, c.rand_fps_hi = int(random_frames_per_step[0]), int(random_frames_per_step[1])   # drawn from the
+        if not (0 < c.rand_fps_lo < c.rand_fps_hi):                                                     # per-env counter stream
+            raise ValueError("random_frames_per_step must be (low, high) with 0 < low < high")           # np.random.randint: low >= high
     c.max_steps = int(max_steps)
     c.warm_start = int(warm_start)
     c.trajectory_saving_period = 5  # ENV:262
@@ -219,10 +225,12 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
                                       f"(supported: {SUPPORTED_SENSOR_CLASSES})")
         order.append((name, cls))
         if cls == "LeaderPositionsTracker_v2":
-            if name != "LeaderPositionsTracker_v2":
-                # use_sensors looks the tracker up by this literal key (CLS:263)
-                raise NotImplementedError("the tracker must be registered under the key 'LeaderPositionsTracker_v2' "
-                                          "(CLS:263 looks it up by name)")
+            if name not in ("LeaderPositionsTracker_v2", "LeaderPositionsTracker"):
+                # use_sensors finds the tracker by these literal keys (CLS:257-267); under either of them the v2 class
+                # is scanned once up front and once more at its dict position (its type name is not the one skipped
+                # at CLS:270) -- the shipped training configs register it as "LeaderPositionsTracker"
+                raise NotImplementedError("the tracker must be registered under the key 'LeaderPositionsTracker_v2' or "
+                                          "'LeaderPositionsTracker' (CLS:257-267 look it up by name)")
             if spec.get("eat_close_points", True):
                 # inherited default eat_close_points=True is never applied by the v2 scan (SEN:243-327)
                 pass
@@ -290,7 +298,7 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
     # trajectory_saving_period frames up to max_steps (+ the frames of the step that crosses it).
     init_pts = int(0.9 * c.max_distance / (5 * l_max)) + 2
     c.init_traj_cap = int(init_traj_cap) if init_traj_cap else ((init_pts + 7) // 8) * 8
-    need = c.init_traj_cap + (c.max_steps + 2 * c.frames_per_step) // 5 + 8
+    need = c.init_traj_cap + (c.max_steps + 2 * max(c.frames_per_step, c.rand_fps_hi)) // 5 + 8
     c.traj_cap = int(traj_cap) if traj_cap else ((need + 63) // 64) * 64
     def pow2(v):
         return 1 << max(3, (int(v) - 1).bit_length())

@@ -42,6 +42,7 @@ int validate(const ftl_config& c, std::string& why) {
     REQ(c.abi_version == FTL_ABI_VERSION, "abi_version %d != %d", c.abi_version, FTL_ABI_VERSION);
     REQ(c.width > 0 && c.height > 0, "bad field size");
     REQ(c.frames_per_step > 0, "frames_per_step must be positive");
+    REQ(c.rand_fps_hi == 0 || (c.rand_fps_lo > 0 && c.rand_fps_lo < c.rand_fps_hi), "random_frames_per_step must be (low, high) with 0 < low < high");
     REQ(c.trajectory_saving_period > 0, "trajectory_saving_period must be positive");
     REQ(c.n_static >= 0 && c.n_static <= 4096, "n_static out of range");
     REQ(c.n_bears >= 0 && c.n_bears <= FTL_MAX_BEARS, "n_bears out of range (0..%d)", FTL_MAX_BEARS);
@@ -102,6 +103,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         rays += cfg->lasers[k].count;
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
+    if (hmax * (P.R - 1) > FTL_WAVE) { delete h; return fail(FTL_E_INVALID, "max_prev_obs x (1 + bears) exceeds one wavefront of snapshot rects"); }
     // the frame kernel stages at most 48 block boxes per env (registers in flight) and 12 KB per wave
     P.bb_in_lds = (cfg->traj_cap / FTL_TRAJ_BLOCK <= 48 && (size_t)(FTL_WAVE / (P.R <= 4 ? 4 : 8)) * (cfg->traj_cap / FTL_TRAJ_BLOCK) * 16 <= 12 * 1024) ? 1 : 0;
     {   // row width / common history of the fused sensorPrev output
@@ -128,7 +130,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         // + ray ends (double2) + per-(ray, snapshot) minima (u64 x HM) + miss readings (f64)
         const size_t rects = (size_t)cfg->n_static + hmax + (size_t)hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
         P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + rects * 20 + (size_t)2 * cfg->corr_cap * 4 + (size_t)2 * hmax * 20 + 64
-                           + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : 8) * 8 + (size_t)rays * 8);
+                           + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : hmax <= 8 ? 8 : FTL_HMAX) * 8 + (size_t)rays * 8);
     }
     if (P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
     *out = h;
@@ -214,7 +216,8 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
     }
     if (h->P.cfg.n_lasers > 0) {
         if (h->P.hmax <= 5) hipLaunchKernelGGL(ftl_rays_kernel<5>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
-        else hipLaunchKernelGGL(ftl_rays_kernel<8>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
+        else if (h->P.hmax <= 8) hipLaunchKernelGGL(ftl_rays_kernel<8>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
+        else hipLaunchKernelGGL(ftl_rays_kernel<FTL_HMAX>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));

@@ -27,7 +27,7 @@
 #include "../../include/ftl.h"
 
 #define FTL_WAVE 64
-#define FTL_HMAX 8          // compile-time cap on max_prev_obs (register accumulators)
+#define FTL_HMAX 12         // compile-time cap on max_prev_obs (the shipped training configs use 10)
 #ifndef FTL_RAYS_WPE
 #define FTL_RAYS_WPE 5      // 96 VGPRs; LDS (7 KB per env) caps the CU at ~22 waves anyway
 #endif

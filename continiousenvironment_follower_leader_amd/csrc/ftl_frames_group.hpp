@@ -83,6 +83,14 @@ __device__ __forceinline__ double d_uniform01(unsigned long long seed, unsigned 
     return (double)(d_mix64(key + 0x9E3779B97F4A7C15ULL * (frame + 1)) >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// device twin of ftl_rand_frames (include/ftl.h): np.random.randint(lo, hi) of ENV:405 / 940
+__device__ __forceinline__ int d_rand_frames(const ftl_config& c, int env, int resets, int step_count) {
+    const double u = d_uniform01(c.rng_seed, (unsigned long long)(c.env_id_base + env), (unsigned long long)resets,
+                                 (unsigned long long)step_count | (1ULL << 40));
+    const int v = c.rand_fps_lo + (int)(u * (double)(c.rand_fps_hi - c.rand_fps_lo));
+    return v < c.rand_fps_hi ? v : c.rand_fps_hi - 1;
+}
+
 // per-lane context: robot r of env `env`, env scalars replicated over the group
 struct GCtx {
     int env, r, slot;
@@ -90,6 +98,7 @@ struct GCtx {
     int scen, cur_target_id, leader_finished, done, crash, is_in_box, is_on_trace, too_close;
     int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
     int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint, green_tiny, resets, acc_consumed;
+    int fps;             // frames of this step: cfg.frames_per_step, or the env's last draw under random_frames_per_step
     double acc_penalty, overall_reward, cur_tx, cur_ty;
     double cur_mult, cur_acc, cum_speed;   // leader regimes (ENV:412, 449, 591-592, 1143-1174)
     float hx, hy;        // coordinates of trajectory point `hint`
@@ -110,6 +119,7 @@ __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
     E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
     E.snap_head = ei[FTL_EI_SNAP_HEAD]; E.hint = ei[FTL_EI_HINT]; E.green_tiny = ei[FTL_EI_GREEN_TINY];
     E.resets = ei[FTL_EI_RESETS]; E.acc_consumed = ei[FTL_EI_ACC_CONSUMED];
+    E.fps = P.cfg.rand_fps_hi > 0 ? ei[FTL_EI_FPS] : P.cfg.frames_per_step;
     E.hx = __int_as_float(ei[FTL_EI_HINT_X]); E.hy = __int_as_float(ei[FTL_EI_HINT_Y]);
     E.clr_g = __int_as_float(ei[FTL_EI_CLR_GREEN]); E.clr_a = __int_as_float(ei[FTL_EI_CLR_ALL]);
     E.cur_mult = ed[FTL_ED_CUR_MULT]; E.cur_acc = ed[FTL_ED_CUR_ACC]; E.cum_speed = ed[FTL_ED_CUM_SPEED];
@@ -142,8 +152,8 @@ __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
         ei[FTL_EI_TRAJ_LEN] = E.traj_len; ei[FTL_EI_TRK_COUNTER] = E.trk_counter; ei[FTL_EI_CORR_LO] = E.corr_lo;
         ei[FTL_EI_CORR_HI] = E.corr_hi; ei[FTL_EI_SEED_END] = E.seed_end; ei[FTL_EI_SNAP_COUNT] = E.snap_count;
         ei[FTL_EI_ERROR] = E.error; ei[FTL_EI_EPISODES] = E.episodes; ei[FTL_EI_GREEN_COUNT] = E.green_count; ei[FTL_EI_GREEN_LEN] = E.green_len;
-        ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SNAP_HEAD] = E.snap_head; ei[FTL_EI_HINT] = E.hint; ei[FTL_EI_GREEN_TINY] = E.green_tiny; ei[FTL_EI_PAD] = 0;
-        ei[FTL_EI_RESETS] = E.resets; ei[FTL_EI_ACC_CONSUMED] = E.acc_consumed;
+        ei[FTL_EI_SCAN_OK] = E.scan_ok; ei[FTL_EI_SNAP_HEAD] = E.snap_head; ei[FTL_EI_HINT] = E.hint; ei[FTL_EI_GREEN_TINY] = E.green_tiny;
+        ei[FTL_EI_RESETS] = E.resets; ei[FTL_EI_ACC_CONSUMED] = E.acc_consumed; ei[FTL_EI_FPS] = E.fps;
         ei[FTL_EI_HINT_X] = __float_as_int(E.hx); ei[FTL_EI_HINT_Y] = __float_as_int(E.hy);
         ei[FTL_EI_CLR_GREEN] = __float_as_int(E.clr_g); ei[FTL_EI_CLR_ALL] = __float_as_int(E.clr_a);
         ed[FTL_ED_CUR_MULT] = E.cur_mult; ed[FTL_ED_CUR_ACC] = E.cur_acc; ed[FTL_ED_CUM_SPEED] = E.cum_speed;
@@ -201,6 +211,7 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         E.green_count = 0; E.green_len = -1; E.green_w = 0.0; E.green_tiny = 0; E.error = 0; E.scan_ok = 0;
         E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0; E.snap_head = 0;
         E.hint = 0; E.hx = 3.0e38f; E.hy = 3.0e38f; E.clr_g = 0.0f; E.clr_a = 0.0f;     // no cached point, no bound
+        if (c.rand_fps_hi > 0 && E.fps == 0) E.fps = d_rand_frames(c, E.env, 0, 0);      // the constructor's draw (ENV:405)
         E.cur_mult = 1.0; E.cur_acc = 0.0; E.cum_speed = 0.0; E.resets += 1;      // ENV:449, 591-592; acc_consumed persists (ENV:1170)
     }
     // group-uniform from here on (go is the same in every lane of a group), so the broadcasts are safe
@@ -221,7 +232,7 @@ template <int G>
 __device__ __forceinline__ void g_build_near(const FtlDevParams& P, GCtx& E, int4* s_near, int* s_cnt) {
     const ftl_config& c = P.cfg;
     const float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py), fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
-    const float F = (float)c.frames_per_step;
+    const float F = (float)(c.rand_fps_hi > 0 ? c.rand_fps_hi : c.frames_per_step);     // most frames a step can have
     const float ml = 0.5f * (float)(c.leader.img_w + c.leader.img_h) + 4.0f + F * (float)fmax(fabs(c.leader.max_speed), fabs(c.leader.min_speed));
     const float mf = 0.5f * (float)(c.follower.img_w + c.follower.img_h) + 4.0f + F * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed));
     if (E.r == 0) s_cnt[E.slot] = 0;
@@ -452,7 +463,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             for (int i = 0; i < c.n_acc_regime; i++)
                 if (!((E.acc_consumed >> i) & 1) && c.acc_key[i] <= E.step_count) { E.cur_acc = c.acc_val[i]; E.cum_speed = E.cur_acc; E.acc_consumed |= 1 << i; }
             E.cum_speed += E.cur_acc;
-            acceleration = (E.cum_speed * c.leader.max_speed) / c.frames_per_step;
+            acceleration = (E.cum_speed * c.leader.max_speed) / E.fps;
         }
         lspeed = speed + acceleration;
     }
@@ -571,9 +582,9 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             // Refresh ahead of need.  A search is paid by the whole wavefront, whichever env asks for it, so the envs whose
             // caches would run out somewhere inside this step (the follower moves at most `reach` until its end, the
             // green window drops at most a few points) all search NOW, in the same frame, instead of in different ones.
-            const float reach = (float)c.frames_per_step * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed)) * 1.001f + 1e-3f;
+            const float reach = (float)E.fps * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed)) * 1.001f + 1e-3f;
             const float hd = sqrtf(hd2);
-            const bool h_stays_green = E.hint >= g_lo + 2 + c.frames_per_step / c.trajectory_saving_period;
+            const bool h_stays_green = E.hint >= g_lo + 2 + E.fps / c.trajectory_saving_period;
             const float eps_lo = (float)(eps * (1.0 - 1e-5)), dev_lo = (float)(mdev * (1.0 - 1e-5));
             bool safe;
             if (fast == 1) safe = h_stays_green && hd + reach < eps_lo;
@@ -689,7 +700,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         if (E.finish_timer < 0) E.finish_timer = 0;
         else {
             E.finish_timer += 1;
-            if (E.finish_timer > c.frames_per_step * 20) { i0 = FTL_MISSION_SUCCESS; i2 = FTL_LEADER_FINISHED; i1 = FTL_AGENT_FINISHED; E.done = 1; }
+            if (E.finish_timer > E.fps * 20) { i0 = FTL_MISSION_SUCCESS; i2 = FTL_LEADER_FINISHED; i1 = FTL_AGENT_FINISHED; E.done = 1; }
         }
     }
     if (E.step_count > c.warm_start) {                      // ENV:1088-1107
@@ -1012,15 +1023,18 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         __syncthreads();
         FTL_TIC(5);
         int tick = (E.step_count + 1) % P.cfg.trajectory_saving_period;
-#pragma nounroll
+        // ENV:935-936; under random_frames_per_step every env has its own frame count this step (group-uniform branch)
 #ifdef FTL_ABLATE_FRAMES
-        for (int f = 0; f < FTL_ABLATE_FRAMES; f++) {
+        const int f_max = FTL_ABLATE_FRAMES;
 #else
-        for (int f = 0; f < P.cfg.frames_per_step; f++) {                       // ENV:935-936
+        const int f_max = P.cfg.rand_fps_hi > 0 ? P.cfg.rand_fps_hi - 1 : P.cfg.frames_per_step;
 #endif
-            g_frame<G>(P, E, L, near, bbl, tick, reward, i0, i1, i2, f == 0);
+#pragma nounroll
+        for (int f = 0; f < f_max; f++) {
+            if (f < E.fps) g_frame<G>(P, E, L, near, bbl, tick, reward, i0, i1, i2, f == 0);
             __syncthreads();          // an appended trajectory point is read by the other lanes of the group next frame
         }
+        if (P.cfg.rand_fps_hi > 0) E.fps = d_rand_frames(P.cfg, E.env, E.resets, E.step_count);      // ENV:939-940: the next step's frames
         if (E.valid && E.r == 0) {
             C.out.reward[E.env] = reward; C.out.done[E.env] = (uint8_t)E.done;
             C.out.status[3 * (size_t)E.env] = (uint8_t)i0; C.out.status[3 * (size_t)E.env + 1] = (uint8_t)i1; C.out.status[3 * (size_t)E.env + 2] = (uint8_t)i2;

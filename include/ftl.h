@@ -118,6 +118,7 @@ typedef struct ftl_config {
     int32_t speed_is_range[FTL_MAX_REGIME];
     int32_t acc_key[FTL_MAX_REGIME];
     int32_t env_id_base;                 /* global index of env 0 of this handle (multi-GPU shards draw distinct streams) */
+    int32_t rand_fps_lo, rand_fps_hi;    /* random_frames_per_step bounds [lo, hi) (ENV:402-405, 939-940); hi == 0: fixed frames_per_step */
     int32_t _pad1;
     double speed_lo[FTL_MAX_REGIME], speed_hi[FTL_MAX_REGIME];
     double acc_val[FTL_MAX_REGIME];
@@ -133,6 +134,14 @@ static inline uint64_t ftl_mix64(uint64_t x) {
 static inline double ftl_uniform01(uint64_t rng_seed, uint64_t env_id, uint64_t resets, uint64_t frame) {
     uint64_t key = ftl_mix64(rng_seed + 0x9E3779B97F4A7C15ULL * (env_id + 1)) ^ ftl_mix64(0xD1B54A32D192ED03ULL * (resets + 1));
     return (double)(ftl_mix64(key + 0x9E3779B97F4A7C15ULL * (frame + 1)) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* np.random.randint(lo, hi) of ENV:405/940 on the same counter stream, in a key range of its own (bit 40 of the frame key):
+ * the draw made after the step that ended at frame `step_count` of episode `resets` (0, 0: the constructor's draw). */
+static inline int32_t ftl_rand_frames(uint64_t rng_seed, uint64_t env_id, uint64_t resets, uint64_t step_count, int32_t lo, int32_t hi) {
+    double u = ftl_uniform01(rng_seed, env_id, resets, step_count | (1ULL << 40));
+    int32_t v = lo + (int32_t)(u * (double)(hi - lo));
+    return v < hi ? v : hi - 1;
 }
 
 /* Scenario pool = output of the reference's reset() (ENV:434-543) for P episodes, device arrays.
@@ -257,7 +266,9 @@ enum {
        coordinates of trajectory point FTL_EI_HINT, and lower bounds on the follower's distance to every green point /
        to every trajectory point */
     FTL_EI_HINT_X, FTL_EI_HINT_Y, FTL_EI_CLR_GREEN, FTL_EI_CLR_ALL,
-    FTL_EI_PAD, FTL_EI_COUNT
+    FTL_EI_FPS,        /* frames of the NEXT step of this env under random_frames_per_step (drawn at the end of a step, ENV:939-940;
+                          kept across resets like the reference's attribute; 0 = not drawn yet) */
+    FTL_EI_COUNT
 };
 /* indices into the "env_dbl" state field; bear waypoints follow at FTL_ED_BEAR_POINTS + 2*b */
 enum { FTL_ED_ACC_PENALTY = 0, FTL_ED_OVERALL_REWARD, FTL_ED_SPARE0, FTL_ED_SPARE1, FTL_ED_BEAR_POINTS,

@@ -76,6 +76,7 @@ typedef struct ftlo_env {
     /* leader regimes (ENV:412, 449, 591-592, 1143-1174) */
     double cur_mult, cur_acc, cum_speed;
     uint32_t acc_consumed;      /* keys the reference deleted from leader_acceleration_regime (never restored) */
+    int fps;                    /* self.frames_per_step under random_frames_per_step (ENV:405, 939-940); 0 = constructor draw pending */
     uint64_t resets;            /* resets of this Game object so far: keys the uniform stream of the episode */
 } ftlo_env;
 
@@ -341,6 +342,9 @@ static double reward_computation(const ftlo_env* e) {
 
 /* ENV:1143-1157.  `random.uniform(lo, hi)` = lo + (hi-lo)*random() is drawn from the counter-based stream of
  * include/ftl.h (the golden generator patches random.uniform with the same function). */
+/* self.frames_per_step: fixed, or the last np.random.randint(lo, hi) draw (ENV:405, 939-940) from the counter stream */
+static int cur_fps(const ftlo_env* e) { return e->cfg.rand_fps_hi > 0 ? e->fps : e->cfg.frames_per_step; }
+
 static double process_leader_speed_regime(ftlo_env* e) {
     const ftl_config* c = &e->cfg;
     int sel = -1;
@@ -394,7 +398,7 @@ static double frame_step(ftlo_env* e, uint8_t info[3]) {
     }
     if (!e->leader_finished) {                                         /* ENV:1048-1058 */
         double speed = (c->n_speed_regime >= 0) ? process_leader_speed_regime(e) : leader->p->max_speed;
-        double acceleration = (c->n_acc_regime >= 0) ? process_leader_acceleration_regime(e) / c->frames_per_step : 0;
+        double acceleration = (c->n_acc_regime >= 0) ? process_leader_acceleration_regime(e) / cur_fps(e) : 0;
         move_to_the_point(leader, e->cur_target[0], e->cur_target[1], 1, speed + acceleration);
     } else {                                                           /* ENV:1062-1065 */
         command_forward(leader, 0); command_turn(leader, 0, 0); info[2] = FTL_LEADER_FINISHED;
@@ -410,7 +414,7 @@ static double frame_step(ftlo_env* e, uint8_t info[3]) {
         if (e->finish_timer < 0) e->finish_timer = 0;
         else {
             e->finish_timer += 1;
-            if (e->finish_timer > c->frames_per_step * 20) {
+            if (e->finish_timer > cur_fps(e) * 20) {
                 info[0] = FTL_MISSION_SUCCESS; info[2] = FTL_LEADER_FINISHED; info[1] = FTL_AGENT_FINISHED; e->done = 1;
             }
         }
@@ -727,6 +731,8 @@ int ftlo_reset(ftlo_env* e, const int32_t* static_rects, const float* robot_pos,
     e->cur_target_id = 1; e->leader_finished = 0; e->finish_timer = -1;          /* ENV:506-514, 542 */
     e->green_count = 0; e->error = 0;
     e->cur_mult = 1; e->cur_acc = 0; e->cum_speed = 0;                               /* ENV:449, 591-592 */
+    if (c->rand_fps_hi > 0 && e->fps == 0)                                       /* the constructor's draw, ENV:405 */
+        e->fps = ftl_rand_frames(c->rng_seed, (uint64_t)c->env_id_base, 0, 0, c->rand_fps_lo, c->rand_fps_hi);
     e->resets += 1;
     if (route_len == 0) { e->done = 1; e->cur_target[0] = (double)e->rb[0].px; e->cur_target[1] = (double)e->rb[0].py; }
     else if (route_len > 1) { e->cur_target[0] = route[2]; e->cur_target[1] = route[3]; }
@@ -752,9 +758,12 @@ int ftlo_step(ftlo_env* e, double a0, double a1, float* obs_num, float* lasers, 
     else if (a1 > 0) command_turn(f, a1, 1);
     else command_turn(f, 0, 0);
     double rew = 0; uint8_t info[3] = {0, 0, 0};
-    for (int k = 0; k < e->cfg.frames_per_step; k++) rew = frame_step(e, info); /* ENV:935-936 */
+    const int nf = cur_fps(e);
+    for (int k = 0; k < nf; k++) rew = frame_step(e, info);            /* ENV:935-936 */
     use_sensors(e, lasers);                                            /* ENV:937 */
     get_obs(e, obs_num, target);                                       /* ENV:938 */
+    if (e->cfg.rand_fps_hi > 0)                                        /* ENV:939-940 */
+        e->fps = ftl_rand_frames(e->cfg.rng_seed, (uint64_t)e->cfg.env_id_base, (uint64_t)e->resets, (uint64_t)e->step_count, e->cfg.rand_fps_lo, e->cfg.rand_fps_hi);
     *reward = rew; *done = (uint8_t)e->done; status[0] = info[0]; status[1] = info[1]; status[2] = info[2];
     return 0;
 }

@@ -95,6 +95,32 @@ CONFIGS = {
                           leader_acceleration_regime=OrderedDict([("0", 0), ("3100", 0.03), ("4500", 0)]),
                           early_stopping={"max_distance_coef": 4, "low_reward": -300},
                           follower_sensors=SENSORS_B), post=None),
+    # config F: env_config.base_env_config of the shipped training run server/config/3c1bc/params.json (also "transformer"):
+    # random_frames_per_step [30, 70], max_prev_obs 10, the v2 tracker registered LAST under the key "LeaderPositionsTracker",
+    # random speed regimes (JSON string keys in the file's sorted order), negative follower speed, 2 bears, early stopping
+    "F": dict(kwargs=dict(add_bear=True, add_obstacles=True, bear_behind=False, bear_max_speed=1.2, bear_number=2,
+                          bear_size=[1.5, 1.5], bridge_size=[140, 40], constant_follower_speed=False,
+                          early_stopping={"low_reward": -300, "max_distance_coef": 3.5}, follower_acceleration=1,
+                          follower_max_rotation_speed=28.65, follower_max_speed=2,
+                          follower_sensors=OrderedDict([
+                              ("LeaderCorridor_lasers_all", dict(laser_length=100, lasers_count=12, max_prev_obs=10, pad_sectors=False,
+                                                                 react_to_green_zone=True, react_to_obstacles=True, react_to_safe_corridor=True,
+                                                                 sensor_class="LeaderCorridor_Prev_lasers_v2", sensor_name="LeaderCorridor_lasers_all",
+                                                                 use_prev_obs=True)),
+                              ("LeaderCorridor_lasers_obstacles", dict(laser_length=150, lasers_count=24, max_prev_obs=10, pad_sectors=False,
+                                                                       react_to_green_zone=False, react_to_obstacles=True, react_to_safe_corridor=False,
+                                                                       sensor_class="LeaderCorridor_Prev_lasers_v2",
+                                                                       sensor_name="LeaderCorridor_lasers_obstacles", use_prev_obs=True)),
+                              ("LeaderPositionsTracker", dict(corridor_length=250, corridor_width=30, eat_close_points=False, generate_corridor=True,
+                                                              saving_period=8, sensor_class="LeaderPositionsTracker_v2",
+                                                              sensor_name="LeaderPositionsTracker", start_corridor_behind_follower=True))]),
+                          follower_size=[1, 1], framerate=5000, game_height=1000, game_width=1500, ignore_follower_collisions=False,
+                          leader_acceleration=1, leader_margin=1, leader_max_rotation_speed=28.65, leader_max_speed=1, leader_size=[4, 2],
+                          leader_speed_regime=OrderedDict([("0", [0.2, 1]), ("1000", [0.5, 1]), ("1500", 0.75), ("200", 1), ("2300", 0),
+                                                           ("2500", 1), ("3000", [0.5, 1]), ("4000", [0.0, 0.5]), ("5000", [0.4, 1])]),
+                          max_dev=1, max_distance=15, max_steps=30000, min_distance=8, move_bear_v4=True, multi_random_bears=False,
+                          multiple_end_points=False, negative_speed=True, obstacle_number=20, path_finding_iterations=15000,
+                          pixels_to_meter=10, random_frames_per_step=[30, 70], step_grid=10, warm_start=0), post=None),
     # three bears (odd index -> _move_bear_v4), sensors of B
     "B3": dict(kwargs=dict(bear_number=3, follower_sensors=SENSORS_B), post=None),
 }
@@ -115,6 +141,16 @@ class Runner:
         cfg = CONFIGS[config_name]
         self.cfg = cfg
         import copy
+        # np.random.randint of random_frames_per_step (ENV:405 in the constructor, ENV:940 at the end of
+        # every step) is replaced by the build's counter stream keyed on (rng_seed=0, env 0, reset number, frame) --
+        # include/ftl.h ftl_rand_frames; installed BEFORE the constructor runs (resets = 0, frame 0 there)
+        from continiousenvironment_follower_leader_amd.abi import rand_frames
+        self.resets = 0
+        self.game = None
+
+        def randint(lo, hi=None, *a, **k):
+            return rand_frames(0, 0, self.resets, 0 if self.game is None else self.game.step_count, int(lo), int(hi))
+        ENV.np.random.randint = randint
         self.game = ENV.Game(**copy.deepcopy(cfg["kwargs"]))
         self.frame = 0
         orig = self.game.frame_step
@@ -129,7 +165,6 @@ class Runner:
         # build's counter-based stream keyed on (rng_seed=0, env 0, reset number, frame) -- include/ftl.h ftl_uniform01
         import random as _random
         from continiousenvironment_follower_leader_amd.abi import uniform01
-        self.resets = 0
 
         def uniform(a, b):
             return a + (b - a) * uniform01(0, 0, self.resets, self.game.step_count)
@@ -352,6 +387,9 @@ EPISODES = [
     ("E_s3_chase", "E", 3, "chase", 700),
     ("E_s5_random", "E", 5, "random", 200),
     ("E_s8_chase", "E", 8, "chase_noisy", 400),
+    ("F_s1_chase", "F", 1, "chase", 120),
+    ("F_s6_random", "F", 6, "random", 60),
+    ("F_s7_chase", "F", 7, "chase_noisy", 100),
 ]
 
 

@@ -42,7 +42,7 @@ def test_hip_matches_reference_episode(name):
     torch.cuda.synchronize()
     lnames = meta["laser_names"]
     # a random speed regime draws from the per-env counter stream (env id in the key): only env 0 replays the episode
-    rnd = any(cfg.c.speed_is_range[i] for i in range(max(cfg.c.n_speed_regime, 0)))
+    rnd = any(cfg.c.speed_is_range[i] for i in range(max(cfg.c.n_speed_regime, 0))) or cfg.c.rand_fps_hi > 0
     envs = [0] if rnd else list(range(n))
     last = envs[-1]
 
@@ -152,17 +152,19 @@ def test_hip_matches_oracle_batch(n_envs, steps, policy):
     env.close()
 
 
-def test_hip_matches_oracle_regimes():
-    """Config E (leader speed / acceleration regimes, ENV:1143-1174) on a batch with distinct env ids: the random
+@pytest.mark.parametrize("prefix,steps", [("E_", 130), ("F_", 40)])
+def test_hip_matches_oracle_regimes(prefix, steps):
+    """Config E (leader speed / acceleration regimes, ENV:1143-1174) and config F (the shipped training config: random
+    frames per step ENV:939-940, ten snapshots of history, random speed regimes) on a batch with distinct env ids: the random
     multiplier stream is the counter-based ftl_uniform01(rng_seed, env_id, resets, frame) on both sides; a second
     reset checks the `resets` key and that consumed acceleration entries persist (ENV:1170)."""
     from oracle import OracleEnv
     from golden_util import config_for, load_episode, scenario_arrays
-    eps = [load_episode(n) for n in episode_names() if n.startswith("E_")]
+    eps = [load_episode(n) for n in episode_names() if n.startswith(prefix)]
     assert eps
     scen = [scenario_arrays(z) for z, _ in eps]
     cfg = config_for(eps[0][1], scen_route_len=max(len(s["route"]) for s in scen), rng_seed=5, env_id_base=1000)
-    assert cfg.c.n_speed_regime > 0 and cfg.c.n_acc_regime > 0
+    assert cfg.c.n_speed_regime > 0 and (cfg.c.n_acc_regime > 0 or cfg.c.rand_fps_hi > 0)
     n_envs = 96
     env = _vec(cfg, n_envs, scen)
     idx = torch.arange(n_envs, dtype=torch.int32) % len(scen)
@@ -174,7 +176,7 @@ def test_hip_matches_oracle_regimes():
         for e, o in enumerate(oras):
             ob = o.reset(**scen[e % len(scen)])
             assert close(env.obs_num[e].cpu().numpy(), ob["num"]).all()
-        for t in range(130):
+        for t in range(steps):
             a = np.stack([rng.uniform(0.6, 1.0, n_envs) * ms, np.clip(rng.normal(0, 0.15 * mr, n_envs), -mr, mr)], 1)
             env.step(torch.tensor(a, dtype=torch.float64, device="cuda:0"))
             num = env.obs_num.cpu().numpy(); las = env.lasers.cpu().numpy(); rew = env.reward.cpu().numpy()
