@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--workload", default="B", choices=["B", "F"],
+                    help="B (default): the configuration the metric is quoted on; F: the reference's shipped training config "
+                         "(random 30-70 frames per step, 10 snapshots of history) on a generated scenario pool -- extra information only")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,9 +114,21 @@ def main():
     meta = json.loads(str(z["meta"]))
     n = a.envs_per_gpu
     # env_id_base: global env ids (keys of the per-env random streams of row a12) stay distinct across ranks
-    cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=int(z["route_len"].max()), env_id_base=rank * n)
+    workload_text = ("config B: %d envs/GPU, 35 rocks + 2 walls + 1 dynamic obstacle, tracker_v2 + LeaderCorridor_Prev_lasers_v2 x2 "
+                     "(12 rays all edges L=100, 24 rays obstacles L=150, H=5), 10 frames/step, auto-reset from a %d-scenario pool "
+                     "captured from the reference's reset()")
+    if a.workload == "B":
+        cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=int(z["route_len"].max()), env_id_base=rank * n)
+        pool_fn = lambda: ScenarioPool.from_npz(cfg, pool_path, device)     # noqa: E731
+    else:
+        from golden_util import load_episode
+        _, mF = load_episode("F_s7_chase")
+        cfg = config_for(mF, scen_route_len=256, env_id_base=rank * n, rng_seed=a.seed)
+        pool_fn = lambda: ScenarioPool.generate(cfg, np.arange(4096) + 100000 * rank, device)     # noqa: E731
+        workload_text = ("config F (server/config/3c1bc): %d envs/GPU, 20 rocks + 2 walls + 2 dynamic obstacles, same sensors with H=10, "
+                         "random 30-70 frames/step, random leader speed regimes, auto-reset from a %d-scenario pool built by the host generator")
     env = VecGame(n, device=device, config=cfg)
-    pool = ScenarioPool.from_npz(cfg, pool_path, device)
+    pool = pool_fn()
     env.load_scenarios(pool)
     # env e of rank r starts from scenario (seed*1000003 + r*n + e) mod P; auto-reset walks on by n_envs
     idx = (torch.arange(n, dtype=torch.int64) + a.seed * 1000003 + rank * n) % pool.n
@@ -160,7 +175,7 @@ def main():
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and a.workload == "B":      # the PMC passes were taken on workload B
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -170,18 +185,15 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "config B: %d envs/GPU, 35 rocks + 2 walls + 1 dynamic obstacle, tracker_v2 + "
-                                   "LeaderCorridor_Prev_lasers_v2 x2 (12 rays all edges L=100, 24 rays obstacles L=150, H=5), "
-                                   "10 frames/step, auto-reset from a %d-scenario pool captured from the reference's reset()"
-                                   % (n, pool.n),
+            "config": {"workload": workload_text % (n, pool.n),
                        "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "independent env shards x%d" % world,
                        "episodes_finished": float(metrics[0].item()), "env_error_flags": float(metrics[2].item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ftl_frames_group_kernel<4> + ftl_rays_kernel<5> (one step = both launches, same stream)",
+                         "kernel": "ftl_frames_group_kernel<4> + ftl_rays_kernel<%d> (one step = both launches, same stream)" % (5 if a.workload == "B" else 12),
                          "kernel_ms": kernel_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == "B":
             line["cpu_baseline"] = cpu_baseline(cfg, pool_path, a.cpu_envs, a.cpu_steps, a.seed)
         print(json.dumps(line), flush=True)
     if dist is not None:
