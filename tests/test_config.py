@@ -66,6 +66,24 @@ def test_constructor_errors(kw, exc):
         make_config(**kw)
 
 
+def test_shipped_training_config_is_accepted():
+    """server/config/3c1bc/params.json: random frames per step, ten snapshots, the v2 tracker under the key
+    'LeaderPositionsTracker' registered last (so the ray sensors scan before its second scan, CLS:255-288)."""
+    z, meta = load_episode("F_s7_chase")
+    with pytest.warns(UserWarning):                      # ENV:399-401 warns that both frame settings are given
+        cfg = config_for(meta)
+    c = cfg.c
+    assert (c.rand_fps_lo, c.rand_fps_hi) == (30, 70) and c.frames_per_step == 10
+    assert cfg.tracker_name == "LeaderPositionsTracker" and [l.after_tracker for l in cfg.lasers] == [False, False]
+    assert [l.history for l in cfg.lasers] == [10, 10] and c.n_speed_regime == 9
+    assert [c.speed_key[i] for i in range(9)] == [0, 1000, 1500, 200, 2300, 2500, 3000, 4000, 5000]      # the file's key order
+    assert c.traj_cap >= (c.max_steps + 2 * 70) // 5                                                        # room for the longest step
+    with pytest.raises(ValueError):
+        make_config(random_frames_per_step=[70, 30])
+    with pytest.raises(NotImplementedError):
+        make_config(random_frames_per_step=[30, 70], frames_per_step=None)
+
+
 def test_unknown_kwargs_are_swallowed_like_the_reference():
     make_config(some_future_flag=1)        # ENV:104 **kwargs
 
