@@ -30,6 +30,10 @@ struct ftl_handle {
     size_t state_bytes;
     Field fields[11];
     bool bound, have_scen;
+    bool regroup;            // envs are regrouped by expected cost after every launch (off: FTL_NO_REGROUP=1, or too many envs)
+    void* rg_mem;            // perm | bh | rank | keys | two key-total buffers (library-owned)
+    int* rg_tot;             // [2][FTL_NKEYS]
+    unsigned rg_parity, rg_launches;
 };
 
 namespace {
@@ -92,6 +96,11 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     h->P.cfg = *cfg;
     h->device = device;
     h->bound = false; h->have_scen = false; h->dP = nullptr; h->dirty = true;
+    h->rg_mem = nullptr; h->rg_tot = nullptr; h->rg_parity = 0; h->rg_launches = 0;
+    {   // the scatter pass reads one histogram row per block of 1024 envs: fine up to a few hundred blocks
+        const char* off = getenv("FTL_NO_REGROUP");
+        h->regroup = !(off && off[0] == '1') && (n_envs + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK <= 512;
+    }
     FtlDevParams& P = h->P;
     P.n_envs = n_envs;
     P.R = 2 + cfg->n_bears;
@@ -139,7 +148,9 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
 
 void ftl_destroy(ftl_handle* h) {
     if (!h) return;
-    if (h->dP) { (void)hipSetDevice(h->device); (void)hipFree(h->dP); }
+    if (h->dP || h->rg_mem) (void)hipSetDevice(h->device);
+    if (h->dP) (void)hipFree(h->dP);
+    if (h->rg_mem) (void)hipFree(h->rg_mem);
     delete h;
 }
 
@@ -199,6 +210,19 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMalloc(params): ") + hipGetErrorString(e));
         h->dirty = true;
     }
+    if (h->regroup && !h->rg_mem) {
+        const size_t n = (size_t)h->P.n_envs, nb = (n + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK;
+        const size_t o_bh = align_up(n * 4, 256), o_rank = o_bh + align_up(nb * FTL_NKEYS * 4, 256), o_keys = o_rank + align_up(n * 2, 256), o_tot = o_keys + align_up(n, 256);
+        e = hipMalloc(&h->rg_mem, o_tot + 2 * FTL_NKEYS * sizeof(int));
+        if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMalloc(regroup): ") + hipGetErrorString(e));
+        char* b = (char*)h->rg_mem;
+        h->P.perm = (int32_t*)b; h->P.bh = (int32_t*)(b + o_bh); h->P.rank = (uint16_t*)(b + o_rank); h->P.keys = (uint8_t*)(b + o_keys);
+        h->rg_tot = (int*)(b + o_tot); h->rg_parity = 0;
+        e = hipMemsetAsync(h->rg_tot, 0, 2 * FTL_NKEYS * sizeof(int), (hipStream_t)stream);
+        if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemsetAsync(regroup): ") + hipGetErrorString(e));
+        hipLaunchKernelGGL(ftl::ftl_perm_identity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->P.perm, (int)n);
+        h->dirty = true;
+    }
     if (h->dirty) {   // only after bind_state / load_scenarios, never on the steady-state step path
         e = hipMemcpy(h->dP, &h->P, sizeof(FtlDevParams), hipMemcpyHostToDevice);
         if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
@@ -218,6 +242,15 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         if (h->P.hmax <= 5) hipLaunchKernelGGL(ftl_rays_kernel<5>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
         else if (h->P.hmax <= 8) hipLaunchKernelGGL(ftl_rays_kernel<8>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
         else hipLaunchKernelGGL(ftl_rays_kernel<FTL_HMAX>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
+    }
+    // the frame kernel left every env's cost class for its next step: rebuild the slot -> env map.  The classes are stable
+    // from step to step unless the frame count is random, so every second launch is enough then.
+    if (h->regroup && (h->P.cfg.rand_fps_hi > 0 || call.mode == 1 || (h->rg_launches++ & 1u) == 0)) {
+        const unsigned nb = (unsigned)((h->P.n_envs + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK);
+        int* tot = h->rg_tot + (h->rg_parity & 1u) * FTL_NKEYS, *tot_next = h->rg_tot + ((h->rg_parity + 1u) & 1u) * FTL_NKEYS;
+        h->rg_parity++;
+        hipLaunchKernelGGL(ftl::ftl_regroup_count_kernel, dim3(nb), dim3(FTL_RG_BLOCK), 0, (hipStream_t)stream, h->dP, tot);
+        hipLaunchKernelGGL(ftl::ftl_regroup_scatter_kernel, dim3(nb), dim3(FTL_RG_BLOCK), 0, (hipStream_t)stream, h->dP, (const int*)tot, tot_next);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));

@@ -41,6 +41,9 @@ struct FtlDevParams {
     float* rb_pos; double* rb_dbl; int32_t* rb_int; int32_t* env_int; double* env_dbl;
     float* traj; double* hist; double* corr; int32_t* snap_rects; int32_t* snap_win;
     float* traj_bb;                   // [n_envs][traj_cap / FTL_TRAJ_BLOCK][4]: xmin, ymin, xmax, ymax of each block of trajectory points
+    // env regrouping (library-owned; null = envs stay bound to their wavefronts): slot -> env, cost class of the next step,
+    // rank inside the block histogram, per-block key histograms
+    int32_t* perm; uint8_t* keys; uint16_t* rank; int32_t* bh;
     ftl_scenarios scen;
 };
 // per-call arguments (passed by value in the kernarg segment)

@@ -395,6 +395,33 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
     }
 }
 
+// What _check_agent_position's cached point and distance bounds already decide (see g_frame): 0 = search needed,
+// 1 = a green point within epsilon, 2 = none within epsilon but one within max_dev, 3 = nothing in reach, 4 = no green
+// point in reach but a trajectory point within epsilon.  `quiet` = the caches also outlast a whole step of `fps` frames
+// (the follower moves at most `reach`, the green window drops at most a few points).
+__device__ __forceinline__ int g_cache_class(const ftl_config& c, const GCtx& E, float fpx, float fpy, int fps, bool& quiet) {
+    const int n = E.traj_len, g_lo = n - 1 - E.green_count;
+    const double eps = c.leader_pos_epsilon, mdev = c.max_dev, far = fmax(mdev, eps);
+    // "some point is clearly within epsilon" => the arg-min point (smallest float32 squared distance) is too
+    const float eps2_lo = (float)(eps * eps * (1.0 - 1e-5)), dev2_lo = (float)(mdev * mdev * (1.0 - 1e-5));
+    const float eps_hi = (float)(eps * (1.0 + 1e-5)) + 1e-3f, far_hi = (float)(far * (1.0 + 1e-5)) + 1e-3f;
+    const bool h_green = E.hint >= g_lo && E.hint <= n - 2;
+    const float dx = E.hx - fpx, dy = E.hy - fpy, hd2 = dx * dx + dy * dy;
+    int fast = 0;
+    if (h_green && hd2 < eps2_lo) fast = 1;
+    else if (h_green && hd2 < dev2_lo && E.clr_g > eps_hi) fast = 2;
+    else if (E.clr_g > far_hi) fast = (E.clr_a > eps_hi) ? 3 : (hd2 < eps2_lo ? 4 : 0);
+    const float reach = (float)fps * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed)) * 1.001f + 1e-3f;
+    const float hd = sqrtf(hd2);
+    const bool h_stays_green = E.hint >= g_lo + 2 + fps / c.trajectory_saving_period;
+    const float eps_lo = (float)(eps * (1.0 - 1e-5)), dev_lo = (float)(mdev * (1.0 - 1e-5));
+    if (fast == 1) quiet = h_stays_green && hd + reach < eps_lo;
+    else if (fast == 2) quiet = h_stays_green && hd + reach < dev_lo && E.clr_g - reach > eps_hi;
+    else if (fast != 0) quiet = E.clr_g - reach > far_hi && (E.clr_a - reach > eps_hi || hd + reach < eps_lo);
+    else quiet = false;
+    return fast;
+}
+
 template <int G>
 __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near, float4* s_bb, int& tick,
                                         double& reward, int& i0, int& i1, int& i2, const bool first) {
@@ -568,34 +595,13 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         const double far = fmax(mdev, eps);
         const float4* bb = s_bb;                              // block bounding boxes, staged in LDS for the step
         const int g_lo = n - 1 - Gc;                           // green points are indices g_lo .. n-2
-        // "some point is clearly within epsilon" => the arg-min point (smallest float32 squared distance) is too
-        const float eps2_lo = (float)(eps * eps * (1.0 - 1e-5)), dev2_lo = (float)(mdev * mdev * (1.0 - 1e-5));
-        const float eps_hi = (float)(eps * (1.0 + 1e-5)) + 1e-3f, far_hi = (float)(far * (1.0 + 1e-5)) + 1e-3f;
-        const bool h_green = E.hint >= g_lo && E.hint <= n - 2;
-        float hd2;
-        { float dx = E.hx - fpx, dy = E.hy - fpy; hd2 = dx * dx + dy * dy; }
-        int fast = 0;
-        if (h_green && hd2 < eps2_lo) fast = 1;                                         // a green point within epsilon
-        else if (h_green && hd2 < dev2_lo && E.clr_g > eps_hi) fast = 2;                // none within epsilon, one within max_dev
-        else if (E.clr_g > far_hi) fast = (E.clr_a > eps_hi) ? 3 : (hd2 < eps2_lo ? 4 : 0);   // no green point in reach
-        if (first && fast != 0) {
-            // Refresh ahead of need.  A search is paid by the whole wavefront, whichever env asks for it, so the envs whose
-            // caches would run out somewhere inside this step (the follower moves at most `reach` until its end, the
-            // green window drops at most a few points) all search NOW, in the same frame, instead of in different ones.
-            const float reach = (float)E.fps * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed)) * 1.001f + 1e-3f;
-            const float hd = sqrtf(hd2);
-            const bool h_stays_green = E.hint >= g_lo + 2 + E.fps / c.trajectory_saving_period;
-            const float eps_lo = (float)(eps * (1.0 - 1e-5)), dev_lo = (float)(mdev * (1.0 - 1e-5));
-            bool safe;
-            if (fast == 1) safe = h_stays_green && hd + reach < eps_lo;
-            else if (fast == 2) safe = h_stays_green && hd + reach < dev_lo && E.clr_g - reach > eps_hi;
-            else safe = E.clr_g - reach > far_hi && (E.clr_a - reach > eps_hi || hd + reach < eps_lo);
-            if (!safe) fast = 0;
-        }
+        const float eps2_lo = (float)(eps * eps * (1.0 - 1e-5));
+        // Refresh ahead of need.  A search is paid by the whole wavefront, whichever env asks for it, so the envs whose
+        // caches would run out somewhere inside this step all search NOW, in the first frame, instead of in different ones.
+        bool quiet;
+        int fast = g_cache_class(c, E, fpx, fpy, E.fps, quiet);
+        if (first && !quiet) fast = 0;
         FTL_PROF(2, E.valid && r == 0 && fast != 0, 1);
-        FTL_PROF(13, E.valid && r == 0 && fast == 0 && h_green && hd2 < dev2_lo, 1);
-        FTL_PROF(14, E.valid && r == 0 && fast == 0 && !(h_green && hd2 < dev2_lo) && E.clr_g <= far_hi, 1);
-        FTL_PROF(15, E.valid && r == 0 && fast == 0 && !(h_green && hd2 < dev2_lo) && E.clr_g > far_hi, 1);
         if (fast == 1) { E.is_on_trace = 1; E.is_in_box = 1; }
         else if (fast == 2) { E.is_in_box = 1; }
         else if (fast == 4) { E.is_on_trace = 1; }
@@ -948,6 +954,55 @@ __device__ __forceinline__ void g_write_obs(const FtlDevParams& P, const FtlCall
     }
 }
 
+
+// ---- env regrouping: counting sort of the envs by P.keys (descending), rebuilt after every frame-kernel launch --------------
+#define FTL_NKEYS 64
+#define FTL_RG_BLOCK 1024
+// pass 1: per block of 1024 envs, count the envs of every key, reserve the block's range inside each key's segment with one
+// atomic per (block, key) (which block comes first inside a key is irrelevant) and give every env its rank in that range.
+// tot = the key totals of this step (one of two buffers, the other one is cleared by pass 2 for the next step).
+__global__ void __launch_bounds__(FTL_RG_BLOCK) ftl_regroup_count_kernel(const FtlDevParams* __restrict__ Pp, int* __restrict__ tot) {
+    const FtlDevParams& P = *Pp;
+    __shared__ int cnt[FTL_RG_BLOCK / FTL_WAVE][FTL_NKEYS];
+    const int t = threadIdx.x, w = t / FTL_WAVE, lane = t % FTL_WAVE;
+    const int env = blockIdx.x * FTL_RG_BLOCK + t;
+    const int key = env < P.n_envs ? (FTL_NKEYS - 1 - (P.keys[env] & (FTL_NKEYS - 1))) : -1;       // descending: expensive envs first
+    int my_rank = 0;
+    for (int k = 0; k < FTL_NKEYS; k++) {
+        const unsigned long long m = __ballot(key == k);
+        if (lane == 0) cnt[w][k] = __popcll(m);
+        if (key == k) my_rank = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    int base = 0;
+    if (key >= 0) for (int ww = 0; ww < w; ww++) base += cnt[ww][key];
+    if (env < P.n_envs) P.rank[env] = (uint16_t)(base + my_rank);
+    if (t < FTL_NKEYS) {
+        int n_k = 0;
+        for (int ww = 0; ww < FTL_RG_BLOCK / FTL_WAVE; ww++) n_k += cnt[ww][t];
+        P.bh[blockIdx.x * FTL_NKEYS + t] = n_k ? atomicAdd(&tot[t], n_k) : 0;      // start of this block's range inside key t
+    }
+}
+// pass 2: slot of an env = (envs of smaller keys) + (start of its block's range inside its key) + its rank
+__global__ void __launch_bounds__(FTL_RG_BLOCK) ftl_regroup_scatter_kernel(const FtlDevParams* __restrict__ Pp, const int* __restrict__ tot, int* __restrict__ tot_next) {
+    const FtlDevParams& P = *Pp;
+    __shared__ int off[FTL_NKEYS];
+    const int t = threadIdx.x;
+    if (t < FTL_NKEYS) {
+        int smaller = 0;
+        for (int k = 0; k < t; k++) smaller += tot[k];
+        off[t] = smaller + P.bh[blockIdx.x * FTL_NKEYS + t];
+        if (blockIdx.x == 0) tot_next[t] = 0;
+    }
+    __syncthreads();
+    const int env = blockIdx.x * FTL_RG_BLOCK + t;
+    if (env < P.n_envs) {
+        const int key = FTL_NKEYS - 1 - (P.keys[env] & (FTL_NKEYS - 1));
+        P.perm[off[key] + P.rank[env]] = env;
+    }
+}
+__global__ void ftl_perm_identity_kernel(int32_t* perm, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) perm[i] = i; }
+
 }  // namespace ftl
 
 #ifndef FTL_FRAMESG_WPE
@@ -962,9 +1017,11 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     constexpr int EPW = FTL_WAVE / G;
     GCtx E;
     E.slot = threadIdx.x / G; E.r = threadIdx.x % G;
-    E.env = blockIdx.x * EPW + E.slot;
-    E.valid = E.env < P.n_envs;
-    if (!E.valid) E.env = P.n_envs - 1;       // idle groups shadow the last env (loads only; every store is guarded)
+    // Envs are not bound to wavefronts: slot -> env goes through the permutation that ftl_regroup_* rebuilt after the last
+    // launch (envs with similar expected cost share a wavefront, expensive ones first); any permutation gives the same results.
+    const int gslot = blockIdx.x * EPW + E.slot;
+    E.valid = gslot < P.n_envs;
+    E.env = E.valid ? (P.perm ? P.perm[gslot] : gslot) : P.n_envs - 1;       // idle groups shadow the last env (loads only; every store is guarded)
     int4* s_near = reinterpret_cast<int4*>(lds);
     int* s_cnt = reinterpret_cast<int*>(lds + (size_t)EPW * P.cfg.n_static * 16);
     float4* s_bb = reinterpret_cast<float4*>(lds + (size_t)EPW * P.cfg.n_static * 16 + (size_t)EPW * 4 + (((size_t)EPW * 4) % 16 ? 16 - ((size_t)EPW * 4) % 16 : 0));
@@ -1057,6 +1114,23 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     FTL_TIC(7);
     g_write_obs<G>(P, C, E);                             // ENV:938
     g_store<G>(P, E);
+    if (P.keys && E.valid) {
+        // cost class of this env's NEXT step, most expensive = largest: frames (random_frames_per_step), searches likely
+        // (caches that will not outlast the step), a tracker scan that saves a point
+        const float fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
+        bool quiet = true;
+        if (E.green_count > 2) (void)g_cache_class(P.cfg, E, fpx, fpy, E.fps, quiet);
+        // tracker: envs whose counters are at most one scan apart save in the same steps and stay together from step to
+        // step (all counters advance by two per step); class 0 = saves in the next step
+        int tc = 0;
+        if (P.cfg.has_tracker) {
+            const int per = P.cfg.tracker_saving_period;
+            tc = (((E.trk_counter + 1) % per) * 4) / per;
+        }
+        int fb = 0;
+        if (P.cfg.rand_fps_hi > 0) fb = ((E.fps - P.cfg.rand_fps_lo) * 8) / (P.cfg.rand_fps_hi - P.cfg.rand_fps_lo);
+        if (E.r == 0) P.keys[E.env] = (uint8_t)((fb << 3) | ((quiet ? 0 : 1) << 2) | (3 - tc));
+    }
     FTL_TIC(10);
 #ifdef FTL_PROFILE_PATHS
     __syncthreads();
