@@ -92,6 +92,30 @@ def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
     g.close()
 
 
+def test_regrouping_never_changes_a_result(monkeypatch):
+    """The slot -> env permutation (envs of similar expected cost share a wavefront) is rebuilt every other launch; with
+    it switched off (FTL_NO_REGROUP=1 at ftl_create) every output and every state field must be bit-identical."""
+    n = 4096 + 37                      # not a multiple of the regroup block or of the envs per wavefront
+    cfg = _pool_cfg(max_steps=300, warm_start=10)
+    a = _vec(n, cfg)
+    monkeypatch.setenv("FTL_NO_REGROUP", "1")
+    b = _vec(n, cfg)
+    monkeypatch.delenv("FTL_NO_REGROUP")
+    idx = torch.arange(n, dtype=torch.int32) % a.pool.n
+    a.reset(idx); b.reset(idx)
+    fields = ["rb_pos", "rb_dbl", "rb_int", "env_int", "env_dbl", "traj", "hist", "corr", "traj_bb"]
+    for t in range(70):
+        act = _actions(cfg, n, 100 + t)
+        a.step(act, auto_reset=True); b.step(act, auto_reset=True)
+        for name in ("obs_num", "lasers", "target", "reward", "done", "status"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (t, name)
+        if t % 10 == 9:
+            for f in fields:
+                assert torch.equal(a.state_field(f), b.state_field(f)), (t, f)
+    assert int(a.state_field("env_int")[:, abi.EI_EPISODES].sum().item()) > 0
+    a.close(); b.close()
+
+
 def test_auto_reset_equals_explicit_reset():
     """An env that finishes under FTL_STEP_AUTO_RESET must continue exactly like a fresh env reset to the next scenario."""
     n = 96
