@@ -33,7 +33,7 @@ struct ftl_handle {
     bool regroup;            // envs are regrouped by expected cost after every launch (off: FTL_NO_REGROUP=1, or too many envs)
     void* rg_mem;            // perm | bh | rank | keys | two key-total buffers (library-owned)
     int* rg_tot;             // [2][FTL_NKEYS]
-    unsigned rg_parity, rg_launches;
+    unsigned rg_parity, rg_launches, rg_every;
 };
 
 namespace {
@@ -99,6 +99,8 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     h->rg_mem = nullptr; h->rg_tot = nullptr; h->rg_parity = 0; h->rg_launches = 0;
     {   // the scatter pass reads one histogram row per block of 1024 envs: fine up to a few hundred blocks
         const char* off = getenv("FTL_NO_REGROUP");
+        const char* ev = getenv("FTL_REGROUP_EVERY");      // tuning knob: rebuild the permutation every k-th launch (default 2)
+        h->rg_every = (ev && atoi(ev) > 0) ? (unsigned)atoi(ev) : 2u;
         h->regroup = !(off && off[0] == '1') && (n_envs + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK <= 512;
     }
     FtlDevParams& P = h->P;
@@ -245,7 +247,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
     }
     // the frame kernel left every env's cost class for its next step: rebuild the slot -> env map.  The classes are stable
     // from step to step unless the frame count is random, so every second launch is enough then.
-    if (h->regroup && (h->P.cfg.rand_fps_hi > 0 || call.mode == 1 || (h->rg_launches++ & 1u) == 0)) {
+    if (h->regroup && (h->P.cfg.rand_fps_hi > 0 || call.mode == 1 || (h->rg_launches++ % h->rg_every) == 0)) {
         const unsigned nb = (unsigned)((h->P.n_envs + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK);
         int* tot = h->rg_tot + (h->rg_parity & 1u) * FTL_NKEYS, *tot_next = h->rg_tot + ((h->rg_parity + 1u) & 1u) * FTL_NKEYS;
         h->rg_parity++;

@@ -98,6 +98,7 @@ struct GCtx {
     int scen, cur_target_id, leader_finished, done, crash, is_in_box, is_on_trace, too_close;
     int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
     int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint, green_tiny, resets, acc_consumed;
+    int n_search;        // frames of this step in which this env needed a trajectory search (regrouping key only)
     int fps;             // frames of this step: cfg.frames_per_step, or the env's last draw under random_frames_per_step
     double acc_penalty, overall_reward, cur_tx, cur_ty;
     double cur_mult, cur_acc, cum_speed;   // leader regimes (ENV:412, 449, 591-592, 1143-1174)
@@ -399,7 +400,7 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
 // 1 = a green point within epsilon, 2 = none within epsilon but one within max_dev, 3 = nothing in reach, 4 = no green
 // point in reach but a trajectory point within epsilon.  `quiet` = the caches also outlast a whole step of `fps` frames
 // (the follower moves at most `reach`, the green window drops at most a few points).
-__device__ __forceinline__ int g_cache_class(const ftl_config& c, const GCtx& E, float fpx, float fpy, int fps, bool& quiet) {
+__device__ __forceinline__ int g_cache_class(const ftl_config& c, const GCtx& E, float fpx, float fpy, int fps, bool want_quiet, bool& quiet) {
     const int n = E.traj_len, g_lo = n - 1 - E.green_count;
     const double eps = c.leader_pos_epsilon, mdev = c.max_dev, far = fmax(mdev, eps);
     // "some point is clearly within epsilon" => the arg-min point (smallest float32 squared distance) is too
@@ -411,6 +412,8 @@ __device__ __forceinline__ int g_cache_class(const ftl_config& c, const GCtx& E,
     if (h_green && hd2 < eps2_lo) fast = 1;
     else if (h_green && hd2 < dev2_lo && E.clr_g > eps_hi) fast = 2;
     else if (E.clr_g > far_hi) fast = (E.clr_a > eps_hi) ? 3 : (hd2 < eps2_lo ? 4 : 0);
+    quiet = false;
+    if (!want_quiet) return fast;                  // (the per-frame caller needs it in the first frame of a step only)
     const float reach = (float)fps * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed)) * 1.001f + 1e-3f;
     const float hd = sqrtf(hd2);
     const bool h_stays_green = E.hint >= g_lo + 2 + fps / c.trajectory_saving_period;
@@ -599,13 +602,19 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         // Refresh ahead of need.  A search is paid by the whole wavefront, whichever env asks for it, so the envs whose
         // caches would run out somewhere inside this step all search NOW, in the first frame, instead of in different ones.
         bool quiet;
-        int fast = g_cache_class(c, E, fpx, fpy, E.fps, quiet);
+        int fast = g_cache_class(c, E, fpx, fpy, E.fps, first, quiet);
         if (first && !quiet) fast = 0;
         FTL_PROF(2, E.valid && r == 0 && fast != 0, 1);
+        FTL_PROF(8, E.valid && r == 0 && !first && fast == 0 && P.keys && (P.keys[E.env] & 0x3c) == 0, 1);
+        FTL_PROF(9, E.valid && r == 0 && first && fast == 0 && P.keys && (P.keys[E.env] & 0x3c) == 0, 1);
+        FTL_PROF(13, E.valid && r == 0 && first && fast == 0, 1);
+        FTL_PROF(14, E.valid && r == 0 && !first && fast == 0, 1);
+        FTL_PROF(15, E.valid && r == 0 && first, 1);
         if (fast == 1) { E.is_on_trace = 1; E.is_in_box = 1; }
         else if (fast == 2) { E.is_in_box = 1; }
         else if (fast == 4) { E.is_on_trace = 1; }
         else if (fast == 0) {
+        E.n_search += 1;
         // hint window: 4*G points around the point that was closest last frame, one memory round trip
         float wbest = __int_as_float(0x7f800000); int widx = 0x7fffffff;      // over the whole window
         float gbest = __int_as_float(0x7f800000); int gidx = 0x7fffffff;      // over its green members (ties -> higher index)
@@ -646,7 +655,6 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         else {
             float gb2; int gi; float2 q; float skip;
             FTL_PROF(3, E.valid && r == 0, 1);
-            FTL_PROF(8, threadIdx.x == 0, 1);
             g_range_argmin<G>(tr, bb, r, fpx, fpy, g_lo, n - 1, (float)(far * far * (1.0 + 1e-5)) + 1e-2f, true, gidx, gbest, gp, gb2, gi, q, skip);
             E.clr_g = sqrtf(fmaxf(fminf(gb2, skip), 0.0f)) * 0.999999f - 1e-3f;       // every green point is at least this far
             FTL_TIC(11);
@@ -663,7 +671,6 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             else {                                             // closest point of the whole trajectory (ENV:1924-1930)
                 float ab2; int ai; float2 q2; float skip2;
                 FTL_PROF(5, E.valid && r == 0, 1);
-                FTL_PROF(9, (threadIdx.x & (G - 1)) == 0 && __ffsll((long long)__ballot(1)) - 1 == (int)threadIdx.x, 1);
                 g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, widx, wbest, wp, ab2, ai, q2, skip2);
                 E.clr_a = sqrtf(fmaxf(fminf(ab2, skip2), 0.0f)) * 0.999999f - 1e-3f;  // every trajectory point is at least this far
                 if (ai != 0x7fffffff) {
@@ -1025,7 +1032,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     int4* s_near = reinterpret_cast<int4*>(lds);
     int* s_cnt = reinterpret_cast<int*>(lds + (size_t)EPW * P.cfg.n_static * 16);
     float4* s_bb = reinterpret_cast<float4*>(lds + (size_t)EPW * P.cfg.n_static * 16 + (size_t)EPW * 4 + (((size_t)EPW * 4) % 16 ? 16 - ((size_t)EPW * 4) % 16 : 0));
-    E.scan_ok = 0; E.near_cnt = 0;
+    E.scan_ok = 0; E.near_cnt = 0; E.n_search = 0;
     const Limits L = lane_limits(P.cfg, E.r);
 #ifdef FTL_PROFILE_PATHS
     if (threadIdx.x < 16) s_cyc[threadIdx.x] = 0;
@@ -1119,7 +1126,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         // (caches that will not outlast the step), a tracker scan that saves a point
         const float fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
         bool quiet = true;
-        if (E.green_count > 2) (void)g_cache_class(P.cfg, E, fpx, fpy, E.fps, quiet);
+        if (E.green_count > 2) (void)g_cache_class(P.cfg, E, fpx, fpy, E.fps, true, quiet);
         // tracker: envs whose counters are at most one scan apart save in the same steps and stay together from step to
         // step (all counters advance by two per step); class 0 = saves in the next step
         int tc = 0;
@@ -1129,7 +1136,12 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         }
         int fb = 0;
         if (P.cfg.rand_fps_hi > 0) fb = ((E.fps - P.cfg.rand_fps_lo) * 8) / (P.cfg.rand_fps_hi - P.cfg.rand_fps_lo);
-        if (E.r == 0) P.keys[E.env] = (uint8_t)((fb << 3) | ((quiet ? 0 : 1) << 2) | (3 - tc));
+        // how often this env searched in the step that just ended predicts the next one better than the caches alone:
+        // envs that hover around a threshold keep doing it
+        int key;
+        if (P.cfg.rand_fps_hi > 0) key = (fb << 3) | ((quiet && E.n_search <= 1 ? 0 : 1) << 2) | (3 - tc);
+        else key = (min(E.n_search, 7) << 3) | ((quiet ? 0 : 1) << 2) | (3 - tc);
+        if (E.r == 0) P.keys[E.env] = (uint8_t)key;
     }
     FTL_TIC(10);
 #ifdef FTL_PROFILE_PATHS

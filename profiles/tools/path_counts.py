@@ -15,7 +15,7 @@ env.reset(((torch.arange(n) // GROUP) % pool.n).to(torch.int32))
 acts = bench.make_actions(cfg, n // GROUP, 16, 0, torch.device("cuda:0")).repeat_interleave(GROUP, dim=1).contiguous()
 out = (C.c_ulonglong * 48)()
 names = ["frames", "Gc>2", "fast path", "green search", "exact walk", "full search", "blocks scanned (green)", "blocks scanned (full)",
-         "waves w/ green search", "waves w/ full search", "search: in eps", "search: in dev", "search: whole-window eps", "fallback: dev-band, eps unproven", "fallback: green bound <= far", "fallback: all bound <= eps"]
+         "later-frame search by an env predicted quiet", "first-frame search by an env predicted quiet", "search: in eps", "search: in dev", "search: whole-window eps", "search in the first frame of a step", "search in a later frame", "first frames"]
 for phase, steps in (("steps 0-30", 30), ("steps 30-150", 120), ("steps 150-250", 100)):
     env.lib.ftl_debug_prof(out, 1); env.lib.ftl_debug_whist((C.c_uint * 128)(), 1)
     for k in range(steps): env.step(acts[k % 16], auto_reset=True)
