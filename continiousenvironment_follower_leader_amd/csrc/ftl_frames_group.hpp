@@ -368,7 +368,6 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
             int k = __ffs(m) - 1; m &= m - 1;
             float kd2 = __shfl(bd2, k, G);
             if (!(kd2 <= bound)) { skipmin = fminf(skipmin, kd2); continue; }   // the bound may have tightened since the mask was formed
-            FTL_PROF(reversed ? 6 : 7, r == 0, 1);
             int s0 = (b0 + k) * FTL_TRAJ_BLOCK;
             int i0 = max(s0, lo), i1 = min(s0 + FTL_TRAJ_BLOCK, hi);
 #pragma unroll 8
@@ -568,7 +567,6 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         if (exact) { int why = (E.green_len != nn - 1) ? 1 : (E.green_count < 1 ? 2 : 3); E.error = (E.error & 0xff) | (why << 8) | ((((E.error >> 16) + 1) & 0xffff) << 16); }
 #endif
 #ifndef FTL_ABLATE_EXACT
-        FTL_PROF(4, E.valid && r == 0 && exact, 1);
         if (exact) Gn = g_green_walk<G>(P, E, W, tiny);
 #endif
         E.green_count = Gn; E.green_w = W; E.green_len = nn; E.green_tiny = tiny;
@@ -603,6 +601,9 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         // caches would run out somewhere inside this step all search NOW, in the first frame, instead of in different ones.
         bool quiet;
         int fast = g_cache_class(c, E, fpx, fpy, E.fps, first, quiet);
+        FTL_PROF(4, E.valid && r == 0 && first && !quiet && fast == 1, 1); FTL_PROF(5, E.valid && r == 0 && first && !quiet && fast == 2, 1);
+        FTL_PROF(6, E.valid && r == 0 && first && !quiet && fast == 3, 1); FTL_PROF(7, E.valid && r == 0 && first && !quiet && fast == 4, 1);
+        FTL_PROF(12, E.valid && r == 0 && first && fast == 0, 1);
         if (first && !quiet) fast = 0;
         FTL_PROF(2, E.valid && r == 0 && fast != 0, 1);
         FTL_PROF(8, E.valid && r == 0 && !first && fast == 0 && P.keys && (P.keys[E.env] & 0x3c) == 0, 1);
@@ -664,13 +665,11 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                 in_dev = !in_eps && euclid_f32_le(fpx, fpy, q.x, q.y, mdev);
             }
             FTL_PROF(10, E.valid && r == 0 && in_eps, 1); FTL_PROF(11, E.valid && r == 0 && in_dev, 1);
-            FTL_PROF(12, E.valid && r == 0 && !in_eps && !in_dev && wbest < eps2_lo, 1);
             if (in_eps) { E.is_on_trace = 1; E.is_in_box = 1; E.hint = gi; E.hx = q.x; E.hy = q.y; }
             else if (in_dev) { E.is_in_box = 1; E.is_on_trace = 0; E.hint = gi; E.hx = q.x; E.hy = q.y; }
             else if (wbest < eps2_lo) { E.is_on_trace = 1; E.is_in_box = 0; E.hint = widx; E.hx = wp.x; E.hy = wp.y; }   // some point is within epsilon
             else {                                             // closest point of the whole trajectory (ENV:1924-1930)
                 float ab2; int ai; float2 q2; float skip2;
-                FTL_PROF(5, E.valid && r == 0, 1);
                 g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, widx, wbest, wp, ab2, ai, q2, skip2);
                 E.clr_a = sqrtf(fmaxf(fminf(ab2, skip2), 0.0f)) * 0.999999f - 1e-3f;  // every trajectory point is at least this far
                 if (ai != 0x7fffffff) {

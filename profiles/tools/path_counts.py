@@ -14,8 +14,8 @@ GROUP = int(os.environ.get("FTL_DIAG_GROUP", "1"))      # >1: make every GROUP c
 env.reset(((torch.arange(n) // GROUP) % pool.n).to(torch.int32))
 acts = bench.make_actions(cfg, n // GROUP, 16, 0, torch.device("cuda:0")).repeat_interleave(GROUP, dim=1).contiguous()
 out = (C.c_ulonglong * 48)()
-names = ["frames", "Gc>2", "fast path", "green search", "exact walk", "full search", "blocks scanned (green)", "blocks scanned (full)",
-         "later-frame search by an env predicted quiet", "first-frame search by an env predicted quiet", "search: in eps", "search: in dev", "search: whole-window eps", "search in the first frame of a step", "search in a later frame", "first frames"]
+names = ["frames", "Gc>2", "fast path", "green search", "not quiet @frame0: on trace", "not quiet @frame0: dev band", "not quiet @frame0: nothing in reach", "not quiet @frame0: old trajectory",
+         "later-frame search by an env predicted quiet", "first-frame search by an env predicted quiet", "search: in eps", "search: in dev", "undecided @frame0", "search in the first frame of a step", "search in a later frame", "first frames"]
 for phase, steps in (("steps 0-30", 30), ("steps 30-150", 120), ("steps 150-250", 100)):
     env.lib.ftl_debug_prof(out, 1); env.lib.ftl_debug_whist((C.c_uint * 128)(), 1)
     for k in range(steps): env.step(acts[k % 16], auto_reset=True)
