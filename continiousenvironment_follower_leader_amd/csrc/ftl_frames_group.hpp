@@ -620,8 +620,13 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         float wbest = __int_as_float(0x7f800000); int widx = 0x7fffffff;      // over the whole window
         float gbest = __int_as_float(0x7f800000); int gidx = 0x7fffffff;      // over its green members (ties -> higher index)
         float2 wp = make_float2(0.0f, 0.0f), gp = wp;                         // their coordinates
+        // the green member FARTHEST AHEAD (largest index: the follower is chasing the leader) that is comfortably inside
+        // epsilon: as the next cached point it stays valid about twice as long as the closest one
+        int aidx = -1; float2 ap = wp;
+        const float reach_a = (float)E.fps * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed)) * 1.001f + 1.0f;
+        const float ahead2 = fmaxf((float)eps * 0.99999f - reach_a, 0.0f) * fmaxf((float)eps * 0.99999f - reach_a, 0.0f);
         {
-            int w0 = E.hint - 2 * G; w0 = w0 < 0 ? 0 : w0;
+            int w0 = E.hint - G; w0 = w0 < 0 ? 0 : w0;                       // a quarter of the window behind the old point, the rest ahead
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int i = w0 + k * G + r;
@@ -631,6 +636,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                     float d2 = dx * dx + dy * dy;
                     if (d2 < wbest) { wbest = d2; widx = i; wp = p; }
                     if (i >= g_lo && i <= n - 2 && d2 <= gbest) { gbest = d2; gidx = i; gp = p; }
+                    if (i >= g_lo + 4 && i <= n - 2 && d2 < ahead2 && i > aidx) { aidx = i; ap = p; }
                 }
             }
 #pragma unroll
@@ -647,10 +653,16 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                 bool take = (ov < gbest) || (ov == gbest && oi != 0x7fffffff && (gidx == 0x7fffffff || oi > gidx));
                 if (take) { gbest = ov; gidx = oi; gp.x = ox; gp.y = oy; }
             }
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) {
+                int oi = __shfl_xor(aidx, off, G); float ox = __shfl_xor(ap.x, off, G), oy = __shfl_xor(ap.y, off, G);
+                if (oi > aidx) { aidx = oi; ap.x = ox; ap.y = oy; }
+            }
         }
         FTL_TIC(8);
         if (gbest < eps2_lo) {                                 // a green point is within epsilon
-            E.is_on_trace = 1; E.is_in_box = 1; E.hint = gidx; E.hx = gp.x; E.hy = gp.y;
+            E.is_on_trace = 1; E.is_in_box = 1;
+            if (aidx >= 0) { E.hint = aidx; E.hx = ap.x; E.hy = ap.y; } else { E.hint = gidx; E.hx = gp.x; E.hy = gp.y; }
         }
 #ifndef FTL_ABLATE_SEARCH
         else {
