@@ -28,6 +28,7 @@
 
 #define FTL_WAVE 64
 #define FTL_HMAX 12         // compile-time cap on max_prev_obs (the shipped training configs use 10)
+#define FTL_WIDE_ARC 8       // segments facing more candidate rays than this are tested by the whole wavefront, one ray per lane
 #ifndef FTL_RAYS_WPE
 #define FTL_RAYS_WPE 5      // 96 VGPRs; LDS (7 KB per env) caps the CU at ~22 waves anyway
 #endif
@@ -608,15 +609,36 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 if (threadIdx.x == 0) { s_rcyc[8] += 1; }
                 { int mc = cnt; for (int o = 32; o >= 1; o >>= 1) mc = max(mc, __shfl_xor(mc, o)); int ni = __popcll(__ballot(m >= 0)); int sc = cnt; for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o); int n4 = __popcll(__ballot(cnt > 4)); if (threadIdx.x == 0) { s_rcyc[9] += mc; s_rcyc[10] += sc; s_rcyc[11] += ni; s_rcyc[12] += (mc <= 2); s_rcyc[13] += (mc > 2 && mc <= 4); s_rcyc[14] += (mc > 4 && mc <= 8); s_rcyc[15] += (mc > 8); } (void)n4; }
 #endif
-                for (int t = 0; t < cnt; t++) {
-                    int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
-                    const double2 e = s_ray[rbase + i];
+                // the reference's intersection test of ray `ray` (index into s_ray / s_best) with segment sgx
+                auto test = [&](int ray, const float4& sgx, unsigned smx) {
+                    const double2 e = s_ray[ray];
                     double d2;
-                    if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sg, d2)) {
+                    if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sgx, d2)) {
                         const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
 #pragma unroll
-                        for (int j = 0; j < HM; j++) if ((sm >> j) & 1u) atomicMin(&s_best[(rbase + i) * HM + j], bits);
+                        for (int j = 0; j < HM; j++) if ((smx >> j) & 1u) atomicMin(&s_best[ray * HM + j], bits);
                     }
+                };
+                // A segment next to the follower faces many rays (up to all N): one lane looping over them would hold the
+                // whole wavefront for that many test iterations.  Such segments (rare: a few per cent of the chunks) are
+                // handed to the wavefront instead -- broadcast the segment, one ray per lane.
+                unsigned long long wide = __ballot(cnt > FTL_WIDE_ARC);
+                while (wide) {
+                    const int L = __ffsll((long long)wide) - 1; wide &= wide - 1;
+                    const float4 sgL = make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.x), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.y), L)),
+                                                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.z), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.w), L)));
+                    const unsigned smL = (unsigned)__builtin_amdgcn_readlane((int)sm, L);
+                    const int i0L = __builtin_amdgcn_readlane(i0, L), cntL = __builtin_amdgcn_readlane(cnt, L);
+                    const int NL = __builtin_amdgcn_readlane(N, L), rbL = __builtin_amdgcn_readlane(rbase, L);
+                    for (int t = lane; t < cntL; t += FTL_WAVE) {
+                        int i = i0L + t; i = i < 0 ? i + NL : (i >= NL ? i - NL : i);
+                        test(rbL + i, sgL, smL);
+                    }
+                }
+                const int own = cnt > FTL_WIDE_ARC ? 0 : cnt;
+                for (int t = 0; t < own; t++) {
+                    int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
+                    test(rbase + i, sg, sm);
                 }
             }
         }
