@@ -154,3 +154,47 @@ class Game:
                 spec = next(l for l in self.cfg.lasers if l.name == name)
                 obs[name] = a.astype(np.float64) if spec.pad_sectors else a   # pad_sectors rows are float64 (SEN:933-953)
         return obs
+
+
+# ---------------------------------------------------------------------------------------------- registry / config files
+# The reference registers its env classes with gym (ENV:2132-2172).  The ids whose classes only fix constructor kwargs map
+# to Game(**kwargs) here; the manual-control ids have no batched counterpart.
+REGISTRY = {
+    "Test-Cont-Env-Auto-v0": dict(),                                                               # TestGameAuto, ENV:1962-1964
+    "Test-Cont-Env-Auto-Follow-no-obstacles-v0": dict(manual_control=False, add_obstacles=False,    # TestGameBaseAlgoNoObst
+                                                      game_width=1500, game_height=1000,
+                                                      early_stopping={"max_distance_coef": 1.2, "low_reward": -100}),
+    "Test-Game-Neat-v0": dict(manual_control=False, add_obstacles=False, discrete_action_space=True,    # TestGameNEAT
+                              early_stopping={"max_distance_coef": 1.2, "low_reward": -100}),
+}
+MANUAL_IDS = ("Test-Cont-Env-Manual-v0", "Test-Cont-Env-Manual-gazebo-v0", "Test-Cont-Env-Manual-hardcore-v0",
+              "Test-Cont-Env-Manual-gazebo-hardcore-v0")
+
+
+def make(env_id, device="cuda:0", scenarios=None, **kwargs):
+    """``gym.make(env_id, **kwargs)`` for the reference's registered ids (same kwargs precedence: the id's own constructor
+    kwargs are fixed, the caller's are passed through where the reference class accepts ``**kwargs``)."""
+    if env_id in MANUAL_IDS:
+        raise NotImplementedError("%s is a manual-control env (pygame event loop); it has no batched counterpart" % env_id)
+    if env_id == "Test-Cont-Env-Auto-Follow-with-obstacles-v0":
+        raise ValueError("To use it, you need to uncomment the call self._get_green_zone_border_points(). Commented out "
+                         "because it slows down the simulation")       # GreenBoxBorderSensor.__init__, SEN:493-495
+    if env_id not in REGISTRY:
+        raise KeyError(env_id)
+    kw = dict(REGISTRY[env_id])
+    if env_id == "Test-Cont-Env-Auto-v0":
+        kw.update(kwargs)                    # TestGameAuto(**kwargs)
+    elif kwargs:
+        raise TypeError("%s takes no constructor arguments in the reference" % env_id)
+    return Game(scenarios=scenarios, device=device, **kw)
+
+
+def kwargs_from_params_json(path):
+    """Game kwargs of an RLlib ``params.json`` of the reference (``env_config.base_env_config``, e.g.
+    src/arctic_gym/server/config/3c1bc/params.json) + the env id and wrapper names next to it.  JSON objects keep their file
+    order, which is the dict order the reference's regimes and sensors depend on."""
+    import json
+    with open(path, "r") as fh:
+        d = json.load(fh, object_pairs_hook=OrderedDict)
+    ec = d.get("env_config", d)
+    return OrderedDict(ec.get("base_env_config", {})), ec.get("name"), list(ec.get("wrappers", []))

@@ -109,3 +109,25 @@ def test_game_facade_fails_loudly_without_a_gpu():
     g = Game(bear_number=1)
     with pytest.raises(FtlError):
         g.reset()
+
+
+def test_registry_and_params_json(tmp_path):
+    import json
+    from continiousenvironment_follower_leader_amd.game import kwargs_from_params_json, make
+    z, meta = load_episode("F_s7_chase")
+    # the layout of the reference's shipped params.json (server/config/3c1bc): env_config.base_env_config + name + wrappers
+    doc = {"env": "continuous-grid", "env_config": {"base_env_config": meta["kwargs"], "name": "Test-Cont-Env-Auto-v0",
+                                                     "wrappers": ["ContinuousObserveModifier_sensorPrev", "SkipBadSeeds"]}}
+    path = tmp_path / "params.json"
+    path.write_text(json.dumps(doc))
+    kw, env_id, wrappers = kwargs_from_params_json(str(path))
+    assert env_id == "Test-Cont-Env-Auto-v0" and wrappers[0] == "ContinuousObserveModifier_sensorPrev"
+    assert list(kw["leader_speed_regime"].keys()) == ["0", "1000", "1500", "200", "2300", "2500", "3000", "4000", "5000"]
+    with pytest.warns(UserWarning):
+        g = make(env_id, **kw)                                  # constructing needs no GPU; reset() would
+    assert g.cfg.c.rand_fps_hi == 70 and g.cfg.tracker_name == "LeaderPositionsTracker"
+    assert make("Test-Game-Neat-v0").action_space.n == 5
+    with pytest.raises(NotImplementedError):
+        make("Test-Cont-Env-Manual-v0")
+    with pytest.raises(KeyError):
+        make("no-such-env")
