@@ -115,8 +115,6 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
     if (hmax * (P.R - 1) > FTL_WAVE) { delete h; return fail(FTL_E_INVALID, "max_prev_obs x (1 + bears) exceeds one wavefront of snapshot rects"); }
-    // the frame kernel stages at most 48 block boxes per env (registers in flight) and 12 KB per wave
-    P.bb_in_lds = (cfg->traj_cap / FTL_TRAJ_BLOCK <= 48 && (size_t)(FTL_WAVE / (P.R <= 4 ? 4 : 8)) * (cfg->traj_cap / FTL_TRAJ_BLOCK) * 16 <= 12 * 1024) ? 1 : 0;
     {   // row width / common history of the fused sensorPrev output
         int w = 0, hcommon = cfg->n_lasers ? cfg->lasers[0].history : 0;
         for (int k = 0; k < cfg->n_lasers; k++) { P.pol_off[k] = w; w += cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1); if (cfg->lasers[k].history != hcommon) hcommon = -1; }
@@ -233,11 +231,11 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
     // frame loop: G lanes per env (4 for <= 2 dynamic obstacles, else 8)
     if (h->P.R <= 4) {
         const int epw = FTL_WAVE / 4;
-        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32 + (h->P.bb_in_lds ? (size_t)epw * (h->P.cfg.traj_cap / FTL_TRAJ_BLOCK) * 16 : 0);
+        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
         hipLaunchKernelGGL(ftl_frames_group_kernel<4>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
     } else {
         const int epw = FTL_WAVE / 8;
-        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32 + (h->P.bb_in_lds ? (size_t)epw * (h->P.cfg.traj_cap / FTL_TRAJ_BLOCK) * 16 : 0);
+        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
         hipLaunchKernelGGL(ftl_frames_group_kernel<8>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
     }
     if (h->P.cfg.n_lasers > 0) {

@@ -36,7 +36,6 @@
 struct FtlDevParams {
     ftl_config cfg;
     int32_t n_envs, R, lasers_len, total_rays, hmax, lds_rays;
-    int32_t bb_in_lds;                // the frame kernel stages the trajectory bounding boxes in LDS (they fit)
     int32_t pol_off[FTL_MAX_LASERS], pol_width, pol_h;   // fused sensorPrev output: column offset per sensor, row width, common history
     // per-env state (views into the caller-owned state buffer), all [n_envs][...]
     float* rb_pos; double* rb_dbl; int32_t* rb_int; int32_t* env_int; double* env_dbl;

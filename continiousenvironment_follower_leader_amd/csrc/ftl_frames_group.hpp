@@ -594,7 +594,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         FTL_PROF(1, E.valid && r == 0, 1);
         const double eps = c.leader_pos_epsilon, mdev = c.max_dev;
         const double far = fmax(mdev, eps);
-        const float4* bb = s_bb;                              // block bounding boxes, staged in LDS for the step
+        const float4* bb = s_bb;                              // block bounding boxes of this env's trajectory (global memory)
         const int g_lo = n - 1 - Gc;                           // green points are indices g_lo .. n-2
         const float eps2_lo = (float)(eps * eps * (1.0 - 1e-5));
         // Refresh ahead of need.  A search is paid by the whole wavefront, whichever env asks for it, so the envs whose
@@ -710,7 +710,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                 float4* bb = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK) + E.traj_len / FTL_TRAJ_BLOCK;
                 float4 box = (E.traj_len % FTL_TRAJ_BLOCK == 0) ? make_float4(lpx, lpy, lpx, lpy) : *bb;
                 box.x = fminf(box.x, lpx); box.y = fminf(box.y, lpy); box.z = fmaxf(box.z, lpx); box.w = fmaxf(box.w, lpy);
-                *bb = box; if (P.bb_in_lds) s_bb[E.traj_len / FTL_TRAJ_BLOCK] = box;
+                *bb = box;
             }
             {   // the new point enters the distance bounds
                 float ax = lpx - fpx, ay = lpy - fpy;
@@ -1042,7 +1042,6 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     E.env = E.valid ? (P.perm ? P.perm[gslot] : gslot) : P.n_envs - 1;       // idle groups shadow the last env (loads only; every store is guarded)
     int4* s_near = reinterpret_cast<int4*>(lds);
     int* s_cnt = reinterpret_cast<int*>(lds + (size_t)EPW * P.cfg.n_static * 16);
-    float4* s_bb = reinterpret_cast<float4*>(lds + (size_t)EPW * P.cfg.n_static * 16 + (size_t)EPW * 4 + (((size_t)EPW * 4) % 16 ? 16 - ((size_t)EPW * 4) % 16 : 0));
     E.scan_ok = 0; E.near_cnt = 0; E.n_search = 0;
     const Limits L = lane_limits(P.cfg, E.r);
 #ifdef FTL_PROFILE_PATHS
@@ -1063,30 +1062,13 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     } else {                                             // step(action): ENV:908-945
         g_load<G>(P, E);
         FTL_TIC(4);
-        // One memory round trip for everything the frames need besides the state: the action, the scenario's static rects
-        // (culled into the near list) and this env's trajectory block boxes are all requested before anything is waited for.
+        // One memory round trip for everything the frames need besides the state: the action and the scenario's static rects
+        // (culled into the near list).
         const double a0 = C.action[2 * (size_t)E.env], a1 = C.action[2 * (size_t)E.env + 1];
-        const int nblk = P.cfg.traj_cap / FTL_TRAJ_BLOCK;
-        float4* bbg = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * nblk;
-        float4* bbl = bbg;
-        constexpr int BBU = 48 / G;                      // bb_in_lds guarantees nblk <= 48 (host side)
-        float4 bbv[BBU];
-        if (P.bb_in_lds) {
-#pragma unroll
-            for (int k = 0; k < BBU; k++) {
-                const int b = k * G + E.r;
-                bbv[k] = (b * FTL_TRAJ_BLOCK < E.traj_len) ? bbg[b] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        // this env's block bounding boxes stay in global memory: the searches that read them are rare now (an LDS copy per
+        // step measured 2 % slower than no copy once the caches of g_frame were in place, and cost 0.6 KB of traffic)
+        float4* bbl = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (P.cfg.traj_cap / FTL_TRAJ_BLOCK);
         g_build_near<G>(P, E, s_near, s_cnt);
-        if (P.bb_in_lds) {
-            bbl = s_bb + (size_t)E.slot * nblk;
-#pragma unroll
-            for (int k = 0; k < BBU; k++) {
-                const int b = k * G + E.r;
-                if (b * FTL_TRAJ_BLOCK < E.traj_len) bbl[b] = bbv[k];
-            }
-        }
         if (E.r == 1) {
             command_forward(E.rb, L, a0);                                   // ENV:927
             if (a1 < 0) command_turn(E.rb, L, fabs(a1), -1);                // ENV:928-933
