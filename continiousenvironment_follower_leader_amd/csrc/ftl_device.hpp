@@ -30,7 +30,7 @@
 #define FTL_HMAX 12         // compile-time cap on max_prev_obs (the shipped training configs use 10)
 #define FTL_WIDE_ARC 8       // segments facing more candidate rays than this are tested by the whole wavefront, one ray per lane
 #ifndef FTL_RAYS_WPE
-#define FTL_RAYS_WPE 5      // 96 VGPRs; LDS (7 KB per env) caps the CU at ~22 waves anyway
+#define FTL_RAYS_WPE 6      // 80 VGPRs without spills; LDS (7 KB per env) caps the CU at ~22 waves, i.e. 5.5 per SIMD
 #endif
 
 struct FtlDevParams {
