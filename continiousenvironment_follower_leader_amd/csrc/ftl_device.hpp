@@ -220,7 +220,9 @@ __device__ __forceinline__ void robot_move(Robot& r, const Limits& L, bool activ
         double vw = fabs(c) * L.img_w + fabs(s) * L.img_h, vh = fabs(s) * L.img_w + fabs(c) * L.img_h;
         double tol = (double)(L.img_w + L.img_h) * 1e-6;
         double fw = vw - floor(vw), fh = vh - floor(vh);
-        bool exact = (rint(a32 / 90.0) * 90.0 == a32) || fw < tol || fw > 1.0 - tol || fh < tol || fh > 1.0 - tol;
+        // multiple of 90?  k = rint(a32 / 90) from a multiplication (an f64 division costs ~35 instructions): if a32 IS a
+        // multiple the product is k(1 + eps) and rounds to k, if it is not no integer k satisfies k * 90 == a32
+        bool exact = (rint(a32 * (1.0 / 90.0)) * 90.0 == a32) || fw < tol || fw > 1.0 - tol || fh < tol || fh > 1.0 - tol;
         int nw = (int)vw, nh = (int)vh;
         if (exact) rotate_size(L.img_w, L.img_h, -direction, nw, nh);
         int cx = rx + (rw >> 1), cy = ry + (rh >> 1);
