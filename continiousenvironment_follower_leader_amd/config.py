@@ -16,7 +16,14 @@ REWARD_DEFAULTS = dict(reward_in_box=1.0, reward_on_track=0.1, reward_in_dev=0.5
                        leader_stop_penalty=-1.0)
 
 # SENSOR_CLASSNAME_TO_CLASS (utils/sensors.py:1291-1307): the classes on the accelerated path.
-SUPPORTED_SENSOR_CLASSES = ("LeaderPositionsTracker_v2", "LeaderCorridor_Prev_lasers_v2")
+SUPPORTED_SENSOR_CLASSES = ("LeaderPositionsTracker_v2", "LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2", "FollowerInfo")
+# classes whose constructor (or scan) raises in the reference itself: exception type and message mirrored (SEN:493-495, 810-864, 993)
+DEPRECATED_SENSOR_CLASSES = {
+    "GreenBoxBorderSensor": (ValueError, "To use it, you need to uncomment the call self._get_green_zone_border_points(). Commented out because it slows down the simulation"),
+    "LeaderObstacles_lasers": (ValueError, "Deprecated class, use LeaderCorridor_lasers_v2 with flags insteadreact_to_safe_corridor=False and react_to_green_zone=False"),
+    "Leader_Dyn_Obstacles_lasers": (ValueError, "Deprecated class, use LeaderCorridor_lasers_v2 with flags insteadreact_to_safe_corridor=False and react_to_green_zone=False, react_to_obstacles='dynamic'"),
+    "LaserPrevSensor": (TypeError, "This is an obsolete class, you should use LeaderCorridor_Prev_lasers_v2 with flags insteadreact_to_safe_corridor=False and react_to_green_zone=False, react_to_obstacles=True and first_laser_angle_offset=0"),
+}
 KNOWN_SENSOR_CLASSES = ("LaserSensor", "LeaderPositionsTracker", "LeaderPositionsTracker_v2",
                         "LeaderTrackDetector_vector", "LeaderTrackDetector_radar", "LeaderCorridor_lasers",
                         "GreenBoxBorderSensor", "LeaderCorridor_lasers_v2", "LeaderObstacles_lasers",
@@ -38,6 +45,7 @@ class LaserSpec:
     after_tracker: bool
     pad_sectors: bool = False
     out_offset: int = 0
+    lenient: bool = False       # LeaderCorridor_lasers_v2: flat [count] observation, no error on a short corridor
 
     @property
     def width(self):            # row width of the sensor's output block (SEN:932-958)
@@ -52,6 +60,7 @@ class GameConfig:
     lasers: list = field(default_factory=list)
     tracker_name: str = None
     sensor_order: list = field(default_factory=list)
+    follower_info: list = field(default_factory=list)       # (name, speed_direction_param) of FollowerInfo sensors
     discrete_action_space: bool = False
     constant_follower_speed: bool = False
     discrete_rotation_speed_to_value: dict = None
@@ -208,7 +217,7 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
          to_px(0.005), to_px(bear_size[1]), to_px(bear_size[0]))      # ENV:706-711
 
     # ---- sensors (CLS:239-253 registry protocol, dict order matters: CLS:269-286) ------------------
-    lasers, tracker_name, order = [], None, []
+    lasers, tracker_name, order, follower_info = [], None, [], []
     seen_tracker = False
     for name, spec in follower_sensors.items():
         spec = dict(spec)
@@ -220,6 +229,9 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
                 raise ValueError(f"Sensor class is undefined: {name}")  # CLS:249
         if cls not in KNOWN_SENSOR_CLASSES:
             raise KeyError(cls)  # SENSOR_CLASSNAME_TO_CLASS[...] lookup, CLS:245
+        if cls in DEPRECATED_SENSOR_CLASSES:
+            exc, msg = DEPRECATED_SENSOR_CLASSES[cls]
+            raise exc(msg)
         if cls not in SUPPORTED_SENSOR_CLASSES:
             raise NotImplementedError(f"sensor class {cls} is outside the accelerated hot path "
                                       f"(supported: {SUPPORTED_SENSOR_CLASSES})")
@@ -243,6 +255,17 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
             c.corridor_width = float(spec["corridor_width"])
             tracker_name = name
             seen_tracker = True
+        elif cls == "FollowerInfo":                  # SEN:822-845: [speed / max_speed, direction / 360], host-side from the state
+            follower_info.append((name, int(spec.get("speed_direction_param", 2))))
+        elif cls == "LeaderCorridor_lasers_v2":      # SEN:736-807: the ray cast on the current edges only, ray 0 straight ahead
+            n = int(spec.get("lasers_count", 12))
+            if n not in (12, 24, 20, 36):
+                raise ValueError("Invalid number of laser beams, should be 12,24,20 or 36")  # SEN:761-762
+            lasers.append(LaserSpec(name=name, count=n, length=float(spec.get("laser_length", 100)),
+                                    react_corridor=bool(spec.get("react_to_safe_corridor", True)),
+                                    react_green=bool(spec.get("react_to_green_zone", False)),
+                                    react_obstacles=_react_code(spec.get("react_to_obstacles", False)),
+                                    history=1, angle_offset=0.0, after_tracker=seen_tracker, pad_sectors=False, lenient=True))
         else:
             n = int(spec.get("lasers_count", 12))
             if n not in (12, 24, 20, 36) and not spec.get("_allow_any_lasers_count", False):
@@ -270,6 +293,7 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
         lc.react_corridor, lc.react_green, lc.react_obstacles = int(l.react_corridor), int(l.react_green), l.react_obstacles
         lc.angle_offset, lc.after_tracker, lc.out_offset = l.angle_offset, int(l.after_tracker), off
         lc.pad_sectors = int(l.pad_sectors)
+        lc.lenient = int(l.lenient)
         off += l.history * l.width
 
     # ---- leader regimes (ENV:382-397): int(key) -> value in dict insertion order ---------------------------------
@@ -314,7 +338,7 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
         c.corr_cap = 16
     c.route_cap = int(route_cap)
 
-    cfg = GameConfig(kwargs=all_kwargs, c=c, lasers=lasers, tracker_name=tracker_name, sensor_order=order,
+    cfg = GameConfig(kwargs=all_kwargs, c=c, lasers=lasers, tracker_name=tracker_name, sensor_order=order, follower_info=follower_info,
                      discrete_action_space=bool(discrete_action_space),
                      constant_follower_speed=bool(constant_follower_speed), pixels_to_meter=pixels_to_meter)
     max_rot = c.follower.max_rotation_speed

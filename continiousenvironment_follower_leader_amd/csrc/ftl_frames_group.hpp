@@ -846,8 +846,11 @@ template <int G>
 __device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
     const ftl_config& c = P.cfg;
     if (!c.has_tracker) { E.scan_ok = 0; return; }
-    int groups = 0;
-    for (int k = 0; k < c.n_lasers; k++) groups |= 1 << (c.lasers[k].after_tracker ? 1 : 0);
+    int groups = 0, strict = 0;       // dict-order groups with a ray sensor / with one that raises on a corridor of <= 1 points
+    for (int k = 0; k < c.n_lasers; k++) {
+        groups |= 1 << (c.lasers[k].after_tracker ? 1 : 0);
+        if (!c.lasers[k].lenient) strict |= 1 << (c.lasers[k].after_tracker ? 1 : 0);
+    }
     int ok = 0, w0lo = 0, w0hi = 0;
     const float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py);
     const float fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
@@ -936,7 +939,7 @@ __device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
         __syncthreads();
         if ((groups >> g) & 1) {
             if (E.corr_hi - E.corr_lo > 1) ok |= 1 << g;
-            else E.error |= FTL_ERR_EMPTY_CORRIDOR;
+            else if ((strict >> g) & 1) E.error |= FTL_ERR_EMPTY_CORRIDOR;      // SEN:893/962 (LeaderCorridor_lasers_v2 does not raise)
         }
         if (g == 0) { w0lo = E.corr_lo; w0hi = E.corr_hi; }
     }

@@ -149,10 +149,15 @@ class Game:
         for name, cls in self.cfg.sensor_order:
             if cls == "LeaderPositionsTracker_v2":
                 obs[name] = v.tracker_obs(0)            # (leader_positions_hist, corridor), SEN:324-325
+            elif cls == "FollowerInfo":
+                obs[name] = v.follower_info(name)[0].cpu().numpy().copy()   # [speed / max_speed, direction / 360] float32, SEN:834-842
             else:
                 a = v.laser_view(name)[0].cpu().numpy().copy()            # [max_prev_obs, lasers_count] float32, SEN:958
                 spec = next(l for l in self.cfg.lasers if l.name == name)
-                obs[name] = a.astype(np.float64) if spec.pad_sectors else a   # pad_sectors rows are float64 (SEN:933-953)
+                if spec.lenient:
+                    obs[name] = a[0]                                      # LeaderCorridor_lasers_v2: [lasers_count] float32, SEN:803-807
+                else:
+                    obs[name] = a.astype(np.float64) if spec.pad_sectors else a   # pad_sectors rows are float64 (SEN:933-953)
         return obs
 
 

@@ -187,6 +187,16 @@ class VecGame:
                 return self.lasers[:, l.out_offset:l.out_offset + l.history * l.width].view(self.n, l.history, l.width)
         raise KeyError(name)
 
+    def follower_info(self, name):
+        """FollowerInfo.scan for every env (SEN:834-842): float32 [n, speed_direction_param] = (follower speed / max_speed,
+        direction / 360, then ones) -- two divisions on the state, done with torch on the device."""
+        k = dict(self.cfg.follower_info)[name]
+        rd = self.state_field("rb_dbl").view(self.n, self.cfg.n_robots, abi.RD_COUNT)[:, 1]
+        out = torch.ones(self.n, k, dtype=torch.float32, device=self.device)
+        out[:, 0] = (rd[:, abi.RD_SPEED] / self.cfg.c.follower.max_speed).to(torch.float32)
+        out[:, 1] = (rd[:, abi.RD_DIRECTION] / 360).to(torch.float32)
+        return out
+
     def state_field(self, name):
         """Typed [n_envs, per_env] view of a named field of the state blob (parity tests / tracker obs)."""
         if name not in self._fields:

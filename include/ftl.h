@@ -74,6 +74,9 @@ typedef struct ftl_laser_cfg {
     int32_t after_tracker;    /* 1: scanned after the tracker's 2nd scan of the step (dict order, CLS:269-286) */
     int32_t out_offset;       /* filled by the library: offset of this sensor's [history][width] block in `lasers` */
     int32_t pad_sectors;      /* SEN:932-953: rows are [front|right|behind|left], 4*count wide, zeros outside a ray's sector */
+    int32_t lenient;          /* 1: LeaderCorridor_lasers_v2 (SEN:736-807) -- one row of the current edges, and a corridor of <= 1 points
+                                 reads laser_length on every ray instead of raising (no FTL_ERR_EMPTY_CORRIDOR) */
+    int32_t _pad;
     double length;            /* laser_length, px */
     double angle_offset;      /* first_laser_angle_offset, deg */
 } ftl_laser_cfg;

@@ -626,7 +626,11 @@ static void laser_scan(ftlo_env* e, int k, float* out) {
     const robot_t* f = &e->rb[1];
     int N = L->count, H = L->history, W = laser_width(L);
     double period = 360.0 / N;
-    if (e->corr_len <= 1) { e->error |= FTL_ERR_EMPTY_CORRIDOR; for (int i = 0; i < H * W; i++) out[i] = (float)L->length; return; }
+    if (e->corr_len <= 1) {          /* SEN:893/962: Prev_lasers_v2 raises UnboundLocalError; lasers_v2 (SEN:779, 803-806) reads laser_length */
+        if (!L->lenient) e->error |= FTL_ERR_EMPTY_CORRIDOR;
+        for (int i = 0; i < H * W; i++) out[i] = (float)L->length;
+        return;
+    }
     if (L->pad_sectors) for (int i = 0; i < H * W; i++) out[i] = 0.0f;   /* np.zeros sector rows, SEN:933-936 */
     /* SEN:896-897 */
     snapshot_t* hs = e->snaps[k];

@@ -121,6 +121,16 @@ CONFIGS = {
                           max_dev=1, max_distance=15, max_steps=30000, min_distance=8, move_bear_v4=True, multi_random_bears=False,
                           multiple_end_points=False, negative_speed=True, obstacle_number=20, path_finding_iterations=15000,
                           pixels_to_meter=10, random_frames_per_step=[30, 70], step_grid=10, warm_start=0), post=None),
+    # config G: B plus the two other live sensor classes -- LeaderCorridor_lasers_v2 (current edges only, ray 0 straight
+    # ahead, no history; SEN:736-807) once before and once after the tracker in dict order, and FollowerInfo (SEN:822-845)
+    "G": dict(kwargs=dict(bear_number=1, follower_sensors=OrderedDict([
+        ("lasers_now_first", {"sensor_class": "LeaderCorridor_lasers_v2", "react_to_obstacles": True, "react_to_green_zone": True,
+                              "react_to_safe_corridor": True, "lasers_count": 20, "laser_length": 120}),
+        ("LeaderPositionsTracker_v2", dict(SENSORS_B["LeaderPositionsTracker_v2"])),
+        ("LeaderCorridor_lasers_all", dict(SENSORS_B["LeaderCorridor_lasers_all"])),
+        ("FollowerInfo", {"sensor_class": "FollowerInfo"}),
+        ("lasers_now", {"sensor_class": "LeaderCorridor_lasers_v2", "react_to_obstacles": "static", "lasers_count": 36,
+                        "laser_length": 150})])), post=None),
     # three bears (odd index -> _move_bear_v4), sensors of B
     "B3": dict(kwargs=dict(bear_number=3, follower_sensors=SENSORS_B), post=None),
 }
@@ -242,7 +252,11 @@ def obs_record(g, obs, laser_names):
            "target": np.array([float(obs["leader_target_point"][0]), float(obs["leader_target_point"][1])])}
     for n in laser_names:
         a = np.asarray(obs[n])
-        rec["laser:" + n] = a.astype(np.float32) if a.dtype == np.float32 else a.astype(np.float64)
+        a = a.astype(np.float32) if a.dtype == np.float32 else a.astype(np.float64)
+        rec["laser:" + n] = a[None, :] if a.ndim == 1 else a       # LeaderCorridor_lasers_v2 returns [N]: stored as one row
+    for n, v in g.follower_sensors.items():
+        if v.get("sensor_class", n) == "FollowerInfo":
+            rec["finfo:" + n] = np.asarray(obs[n], dtype=np.float32)
     return rec
 
 
@@ -301,7 +315,8 @@ def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_do
     r = Runner(config_name)
     obs0 = r.reset(seed)
     g = r.game
-    laser_names = [k for k, v in g.follower_sensors.items() if v.get("sensor_class", k) == "LeaderCorridor_Prev_lasers_v2"]
+    laser_names = [k for k, v in g.follower_sensors.items()
+                   if v.get("sensor_class", k) in ("LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2")]
     scen = scenario_of(g)
     out = {"scen:" + k: v for k, v in scen.items()}
     for k, v in obs_record(g, obs0, laser_names).items():
@@ -387,6 +402,8 @@ EPISODES = [
     ("E_s3_chase", "E", 3, "chase", 700),
     ("E_s5_random", "E", 5, "random", 200),
     ("E_s8_chase", "E", 8, "chase_noisy", 400),
+    ("G_s2_chase", "G", 2, "chase", 120),
+    ("G_s5_random", "G", 5, "random", 120),
     ("F_s1_chase", "F", 1, "chase", 120),
     ("F_s6_random", "F", 6, "random", 60),
     ("F_s7_chase", "F", 7, "chase_noisy", 100),

@@ -67,7 +67,7 @@ def test_game_facade_replays_a_reference_episode():
     g.close()
 
 
-@pytest.mark.parametrize("name", ["B_s3_chase_noisy", "E_s5_random", "D_s2_chase", "F_s7_chase"])
+@pytest.mark.parametrize("name", ["B_s3_chase_noisy", "E_s5_random", "D_s2_chase", "F_s7_chase", "G_s2_chase"])
 def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
     """The whole drop-in: Game(**kwargs); seed(s); reset(); step(a)... reproduces the reference's episode with the
     scenario built by the host-side generator from the python seed alone (nothing captured from the reference)."""
@@ -89,6 +89,11 @@ def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
             assert close(obs[ln], z["obs:laser:" + ln][t]).all()
         assert obs["leader_target_point"] == tuple(z["obs:target"][t])
         assert abs(rew - z["reward"][t]) <= 1e-5 and done == bool(z["done"][t])
+        for fname, _k in g.cfg.follower_info:
+            assert obs[fname].dtype == np.float32 and np.array_equal(obs[fname], z["obs:finfo:" + fname][t])
+    if name.startswith("G_"):      # LeaderCorridor_lasers_v2 returns one row [lasers_count], in the dict position of the sensor
+        assert list(obs.keys()) == ["numerical_features", "leader_target_point"] + list(kw["follower_sensors"].keys())
+        assert obs["lasers_now"].shape == (36,) and obs["lasers_now_first"].shape == (20,)
     g.close()
 
 

@@ -57,6 +57,11 @@ def test_hip_matches_reference_episode(name):
             assert got.shape[1:] == ref.shape
             for e in envs:
                 assert close(got[e], ref).all(), (name, t, e, ln, np.abs(got[e] - ref).max())
+        for name, _k in cfg.follower_info:          # FollowerInfo (SEN:822-845), host-side from the device state
+            fref = z[tag + ":finfo:" + name] if t is None else z[tag + ":finfo:" + name][t]
+            got = env.follower_info(name).cpu().numpy()
+            for e in envs:
+                assert np.array_equal(got[e], fref), (name, t, e, got[e], fref)
         reft = z[tag + ":target"] if t is None else z[tag + ":target"][t]
         assert np.array_equal(env.target.cpu().numpy()[0], reft), (name, t, "target")
 
