@@ -50,7 +50,8 @@ class LaserCfg(C.Structure):
     _fields_ = [("count", C.c_int32), ("react_corridor", C.c_int32), ("react_green", C.c_int32),
                 ("react_obstacles", C.c_int32), ("history", C.c_int32), ("after_tracker", C.c_int32),
                 ("out_offset", C.c_int32), ("pad_sectors", C.c_int32), ("lenient", C.c_int32), ("_pad", C.c_int32),
-                ("length", C.c_double), ("angle_offset", C.c_double)]
+                ("length", C.c_double), ("angle_offset", C.c_double),
+                ("explicit_angles", C.c_int32), ("_pad2", C.c_int32), ("ray_angles", C.c_double * 8)]
 
 
 class Config(C.Structure):

@@ -16,7 +16,7 @@ REWARD_DEFAULTS = dict(reward_in_box=1.0, reward_on_track=0.1, reward_in_dev=0.5
                        leader_stop_penalty=-1.0)
 
 # SENSOR_CLASSNAME_TO_CLASS (utils/sensors.py:1291-1307): the classes on the accelerated path.
-SUPPORTED_SENSOR_CLASSES = ("LeaderPositionsTracker_v2", "LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2", "FollowerInfo")
+SUPPORTED_SENSOR_CLASSES = ("LeaderPositionsTracker_v2", "LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2", "LeaderCorridor_lasers", "FollowerInfo")
 # classes whose constructor (or scan) raises in the reference itself: exception type and message mirrored (SEN:493-495, 810-864, 993)
 DEPRECATED_SENSOR_CLASSES = {
     "GreenBoxBorderSensor": (ValueError, "To use it, you need to uncomment the call self._get_green_zone_border_points(). Commented out because it slows down the simulation"),
@@ -46,6 +46,7 @@ class LaserSpec:
     pad_sectors: bool = False
     out_offset: int = 0
     lenient: bool = False       # LeaderCorridor_lasers_v2: flat [count] observation, no error on a short corridor
+    ray_angles: tuple = None    # LeaderCorridor_lasers: explicit ray directions relative to the heading, deg
 
     @property
     def width(self):            # row width of the sensor's output block (SEN:932-958)
@@ -257,6 +258,17 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
             seen_tracker = True
         elif cls == "FollowerInfo":                  # SEN:822-845: [speed / max_speed, direction / 360], host-side from the state
             follower_info.append((name, int(spec.get("speed_direction_param", 2))))
+        elif cls == "LeaderCorridor_lasers":         # SEN:571-702: 3 or 5 front rays, optionally 2 rear ones, current edges only
+            front, back = int(spec.get("front_lasers_count", 3)), int(spec.get("back_lasers_count", 0))
+            assert front in [3, 5]                   # SEN:596-597
+            assert back in [0, 2]
+            angles = (-40.0, 0.0, 40.0) + ((-90.0, 90.0) if front == 5 else ()) + ((-150.0, 150.0) if back == 2 else ())
+            lasers.append(LaserSpec(name=name, count=front + back, length=float(spec.get("laser_length", 100)),
+                                    react_corridor=bool(spec.get("react_to_safe_corridor", True)),
+                                    react_green=bool(spec.get("react_to_green_zone", False)),
+                                    react_obstacles=_react_code(spec.get("react_to_obstacles", False)),
+                                    history=1, angle_offset=0.0, after_tracker=seen_tracker, pad_sectors=False, lenient=True,
+                                    ray_angles=angles))
         elif cls == "LeaderCorridor_lasers_v2":      # SEN:736-807: the ray cast on the current edges only, ray 0 straight ahead
             n = int(spec.get("lasers_count", 12))
             if n not in (12, 24, 20, 36):
@@ -294,6 +306,9 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
         lc.angle_offset, lc.after_tracker, lc.out_offset = l.angle_offset, int(l.after_tracker), off
         lc.pad_sectors = int(l.pad_sectors)
         lc.lenient = int(l.lenient)
+        lc.explicit_angles = int(l.ray_angles is not None)
+        for i, a in enumerate(l.ray_angles or ()):
+            lc.ray_angles[i] = a
         off += l.history * l.width
 
     # ---- leader regimes (ENV:382-397): int(key) -> value in dict insertion order ---------------------------------

@@ -506,14 +506,15 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             int n_rays = 0;
             for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) n_rays += c.lasers[k].count;
             for (int g = lane; g < n_rays; g += FTL_WAVE) {
-                int i = g; double len = 0, aoff = 0, period = 0; bool found = false;
+                int i = g; double len = 0, aoff = 0, period = 0; bool found = false; int kk = 0;
                 for (int k = 0; k < c.n_lasers; k++) {
                     if (c.lasers[k].after_tracker != which) continue;
                     const int N = c.lasers[k].count;
-                    if (!found && i < N) { found = true; len = c.lasers[k].length; aoff = c.lasers[k].angle_offset; period = 360.0 / (double)N; }
+                    if (!found && i < N) { found = true; kk = k; len = c.lasers[k].length; aoff = c.lasers[k].angle_offset; period = 360.0 / (double)N; }
                     if (!found) i -= N;
                 }
                 double s, co;
+                if (c.lasers[kk].explicit_angles) { aoff = c.lasers[kk].ray_angles[i]; period = 0.0; }     // SEN:609-632: direction + fixed angle
                 sincos_bounded(((fdir + aoff) + i * period) * kDeg2Rad, s, co);
                 const double ex = (double)cx + co * len, ey = (double)cy + s * len;
                 s_ray[g] = make_double2(ex, ey);
@@ -544,7 +545,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             for (int w0 = 0; w0 < n_items; w0 += FTL_WAVE) {
                 const int w = w0 + lane;
                 // decode w -> (sensor k, class q, index m within the class); per-lane sensor parameters
-                int m = -1, mq = 0, N = 1, rbase = 0; float lenf = 0.0f, phi0 = 0.0f;
+                int m = -1, mq = 0, N = 1, rbase = 0; float lenf = 0.0f, phi0 = 0.0f; bool expl = false;
                 {
                     int rem = w, rb = 0;
                     for (int k = 0; k < c.n_lasers; k++) {
@@ -556,7 +557,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                             const int cq = on[q] ? (q < 2 ? 4 * s_cnt[q] : s_cnt[q]) : 0;
                             if (m < 0 && rem >= 0 && rem < cq && w < n_items) {
                                 m = rem; mq = q; N = c.lasers[k].count; rbase = rb; lenf = (float)c.lasers[k].length;
-                                phi0 = (float)((fdir + c.lasers[k].angle_offset) * kDeg2Rad);
+                                phi0 = (float)((fdir + c.lasers[k].angle_offset) * kDeg2Rad); expl = c.lasers[k].explicit_angles != 0;
                             }
                             rem -= cq;
                         }
@@ -596,8 +597,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     float nx = ax + tt * ex_, ny = ay + tt * ey_;
                     float dmin2 = nx * nx + ny * ny;
                     const float reachf = lenf + 2.0f;
-                    if (dmin2 < 4.0f || wd > 0.5f * fN - 0.05f) { i0 = 0; cnt = N; }      // through / next to the origin: every ray
-                    else if (dmin2 > reachf * reachf) { i0 = 0; cnt = 0; }                // wholly beyond this sensor's reach
+                    if (dmin2 > reachf * reachf) { i0 = 0; cnt = 0; }                     // wholly beyond this sensor's reach
+                    else if (expl || dmin2 < 4.0f || wd > 0.5f * fN - 0.05f) { i0 = 0; cnt = N; }   // through / next to the origin, or rays
+                                                                                          // at explicit angles (<= 7 of them): every ray
                     else {
                         const float slack = 0.02f + 0.01f * fN * 0.15915494f;             // >= 0.01 rad, far above float error
                         i0 = (int)ceilf(start - slack);

@@ -79,6 +79,9 @@ typedef struct ftl_laser_cfg {
     int32_t _pad;
     double length;            /* laser_length, px */
     double angle_offset;      /* first_laser_angle_offset, deg */
+    int32_t explicit_angles;  /* 1: LeaderCorridor_lasers (SEN:571-702) -- ray i points at direction + ray_angles[i] instead of a full circle */
+    int32_t _pad2;
+    double ray_angles[8];     /* deg: -40, 0, 40 [, -90, 90] [, -150, 150] (SEN:609-632) */
 } ftl_laser_cfg;
 
 /* Game(**kwargs) after unit conversion (ENV:45-105, 283-357) */

@@ -639,7 +639,8 @@ static void laser_scan(ftlo_env* e, int k, float* out) {
     hs[H - 1].segs = collect_obstacle_edges(e, L, &hs[H - 1].n);
     hs[H - 1].valid = 1;
     for (int i = 0; i < N; i++) {
-        double th = ((f->direction + L->angle_offset) + i * period) * DEG2RAD;     /* SEN:888-891 */
+        /* SEN:888-891; LeaderCorridor_lasers (SEN:609-632): direction + a fixed angle per ray */
+        double th = (L->explicit_angles ? (f->direction + L->ray_angles[i]) : ((f->direction + L->angle_offset) + i * period)) * DEG2RAD;
         double ex = (double)f->px + cos(th) * L->length, ey = (double)f->py + sin(th) * L->length;
         for (int j = 0; j < H; j++) {
             double bx = ex, by = ey; int found = 0; double best = 0;

@@ -130,7 +130,9 @@ CONFIGS = {
         ("LeaderCorridor_lasers_all", dict(SENSORS_B["LeaderCorridor_lasers_all"])),
         ("FollowerInfo", {"sensor_class": "FollowerInfo"}),
         ("lasers_now", {"sensor_class": "LeaderCorridor_lasers_v2", "react_to_obstacles": "static", "lasers_count": 36,
-                        "laser_length": 150})])), post=None),
+                        "laser_length": 150}),
+        ("LeaderCorridor_lasers", {"react_to_obstacles": True, "react_to_green_zone": True, "front_lasers_count": 5,
+                                   "back_lasers_count": 2, "laser_length": 90})])), post=None),
     # three bears (odd index -> _move_bear_v4), sensors of B
     "B3": dict(kwargs=dict(bear_number=3, follower_sensors=SENSORS_B), post=None),
 }
@@ -316,7 +318,7 @@ def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_do
     obs0 = r.reset(seed)
     g = r.game
     laser_names = [k for k, v in g.follower_sensors.items()
-                   if v.get("sensor_class", k) in ("LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2")]
+                   if v.get("sensor_class", k) in ("LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2", "LeaderCorridor_lasers")]
     scen = scenario_of(g)
     out = {"scen:" + k: v for k, v in scen.items()}
     for k, v in obs_record(g, obs0, laser_names).items():

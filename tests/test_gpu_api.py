@@ -93,7 +93,7 @@ def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
             assert obs[fname].dtype == np.float32 and np.array_equal(obs[fname], z["obs:finfo:" + fname][t])
     if name.startswith("G_"):      # LeaderCorridor_lasers_v2 returns one row [lasers_count], in the dict position of the sensor
         assert list(obs.keys()) == ["numerical_features", "leader_target_point"] + list(kw["follower_sensors"].keys())
-        assert obs["lasers_now"].shape == (36,) and obs["lasers_now_first"].shape == (20,)
+        assert obs["lasers_now"].shape == (36,) and obs["lasers_now_first"].shape == (20,) and obs["LeaderCorridor_lasers"].shape == (7,)
     g.close()
 
 
