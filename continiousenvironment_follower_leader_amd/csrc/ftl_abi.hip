@@ -139,7 +139,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         // + ray ends (double2) + per-(ray, snapshot) minima (u64 x HM) + miss readings (f64)
         const size_t rects = (size_t)cfg->n_static + hmax + (size_t)hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
         P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + rects * 20 + (size_t)2 * cfg->corr_cap * 4 + (size_t)2 * hmax * 20 + 64
-                           + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : hmax <= 8 ? 8 : hmax <= 10 ? 10 : FTL_HMAX) * 8 + (size_t)rays * 8);
+                           + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : FTL_HMAX) * 8      /* >= the HM of whichever instantiation launch() picks */ + (size_t)rays * 8);
     }
     if (P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
     *out = h;
@@ -239,10 +239,17 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         hipLaunchKernelGGL(ftl_frames_group_kernel<8>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
     }
     if (h->P.cfg.n_lasers > 0) {
-        if (h->P.hmax <= 5) hipLaunchKernelGGL(ftl_rays_kernel<5>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
-        else if (h->P.hmax <= 8) hipLaunchKernelGGL(ftl_rays_kernel<8>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
-        else if (h->P.hmax <= 10) hipLaunchKernelGGL(ftl_rays_kernel<10>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);   // the shipped training configs
-        else hipLaunchKernelGGL(ftl_rays_kernel<FTL_HMAX>, dim3(h->P.n_envs), dim3(FTL_WAVE), h->P.lds_rays, (hipStream_t)stream, h->dP, call);
+        bool expl = false;
+        for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0;
+        const dim3 grid(h->P.n_envs), block(FTL_WAVE);
+        hipStream_t s = (hipStream_t)stream;
+        if (expl) {        // LeaderCorridor_lasers somewhere in the config: the two instantiations that carry its code
+            if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, true>), grid, block, h->P.lds_rays, s, h->dP, call);
+            else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, true>), grid, block, h->P.lds_rays, s, h->dP, call);
+        } else if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, false>), grid, block, h->P.lds_rays, s, h->dP, call);
+        else if (h->P.hmax <= 8) hipLaunchKernelGGL((ftl_rays_kernel<8, false>), grid, block, h->P.lds_rays, s, h->dP, call);
+        else if (h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false>), grid, block, h->P.lds_rays, s, h->dP, call);   // the shipped training configs
+        else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, false>), grid, block, h->P.lds_rays, s, h->dP, call);
     }
     // the frame kernel left every env's cost class for its next step: rebuild the slot -> env map.  The classes are stable
     // from step to step unless the frame count is random, so every second launch is enough then.

@@ -350,7 +350,8 @@ __shared__ unsigned long long s_rcyc[16];
 #define FTL_RTIC_INIT do { } while (0)
 #endif
 
-template <int HM>
+// EXPL = some sensor has rays at explicit angles (LeaderCorridor_lasers): compiled apart so that the common kernels carry none of it
+template <int HM, bool EXPL = false>
 __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
     using namespace ftl;
@@ -514,7 +515,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     if (!found) i -= N;
                 }
                 double s, co;
-                if (c.lasers[kk].explicit_angles) { aoff = c.lasers[kk].ray_angles[i]; period = 0.0; }     // SEN:609-632: direction + fixed angle
+                if (EXPL && c.lasers[kk].explicit_angles) { aoff = c.lasers[kk].ray_angles[i]; period = 0.0; }     // SEN:609-632: direction + fixed angle
                 sincos_bounded(((fdir + aoff) + i * period) * kDeg2Rad, s, co);
                 const double ex = (double)cx + co * len, ey = (double)cy + s * len;
                 s_ray[g] = make_double2(ex, ey);
@@ -557,7 +558,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                             const int cq = on[q] ? (q < 2 ? 4 * s_cnt[q] : s_cnt[q]) : 0;
                             if (m < 0 && rem >= 0 && rem < cq && w < n_items) {
                                 m = rem; mq = q; N = c.lasers[k].count; rbase = rb; lenf = (float)c.lasers[k].length;
-                                phi0 = (float)((fdir + c.lasers[k].angle_offset) * kDeg2Rad); expl = c.lasers[k].explicit_angles != 0;
+                                phi0 = (float)((fdir + c.lasers[k].angle_offset) * kDeg2Rad); expl = EXPL && c.lasers[k].explicit_angles != 0;
                             }
                             rem -= cq;
                         }
