@@ -240,10 +240,10 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
     }
     if (h->P.cfg.n_lasers > 0) {
         bool expl = false;
-        for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0;
+        for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0 || h->P.cfg.lasers[k].pad_sectors != 0;
         const dim3 grid(h->P.n_envs), block(FTL_WAVE);
         hipStream_t s = (hipStream_t)stream;
-        if (expl) {        // LeaderCorridor_lasers somewhere in the config: the two instantiations that carry its code
+        if (expl) {        // LeaderCorridor_lasers or pad_sectors somewhere in the config: the two instantiations that carry that code
             if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, true>), grid, block, h->P.lds_rays, s, h->dP, call);
             else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, true>), grid, block, h->P.lds_rays, s, h->dP, call);
         } else if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, false>), grid, block, h->P.lds_rays, s, h->dP, call);

@@ -350,7 +350,8 @@ __shared__ unsigned long long s_rcyc[16];
 #define FTL_RTIC_INIT do { } while (0)
 #endif
 
-// EXPL = some sensor has rays at explicit angles (LeaderCorridor_lasers): compiled apart so that the common kernels carry none of it
+// EXPL = the config uses one of the rarer sensor features -- rays at explicit angles (LeaderCorridor_lasers) or the pad_sectors
+// row layout: compiled apart so that the common kernels carry none of that code (it cost 3 % even when never executed)
 template <int HM, bool EXPL = false>
 __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -658,7 +659,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         {
             float* pol = C.out.policy_obs ? C.out.policy_obs + (size_t)env * P.pol_h * P.pol_width : nullptr;
             bool any_pad = false;
-            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which && c.lasers[k].pad_sectors) {
+            for (int k = 0; k < c.n_lasers; k++) if (EXPL && c.lasers[k].after_tracker == which && c.lasers[k].pad_sectors) {
                 any_pad = true;
                 const int tot = c.lasers[k].history * 4 * c.lasers[k].count;
                 for (int i = lane; i < tot; i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = 0.0f;
@@ -680,7 +681,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                         const int np = c.lasers[k].count * c.lasers[k].history;
                         if (!found && q < np) {
                             found = true; N = c.lasers[k].count; H = c.lasers[k].history; ooff = c.lasers[k].out_offset; rb = rbase;
-                            pad = c.lasers[k].pad_sectors != 0; flen = (float)c.lasers[k].length; poff = P.pol_off[k];   // python number / float32 array -> float32 division
+                            pad = EXPL && c.lasers[k].pad_sectors != 0; flen = (float)c.lasers[k].length; poff = P.pol_off[k];   // python number / float32 array -> float32 division
                         }
                         if (!found) q -= np;
                         rbase += c.lasers[k].count;
