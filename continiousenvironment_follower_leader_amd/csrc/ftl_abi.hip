@@ -228,15 +228,21 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
         h->dirty = false;
     }
-    // frame loop: G lanes per env (4 for <= 2 dynamic obstacles, else 8)
-    if (h->P.R <= 4) {
-        const int epw = FTL_WAVE / 4;
+    // frame loop: G lanes per env (4 for <= 2 dynamic obstacles, else 8); configs with leader regimes or random frame counts
+    // use the instantiations that carry that code
+    {
+        const bool reg = h->P.cfg.n_speed_regime >= 0 || h->P.cfg.n_acc_regime >= 0 || h->P.cfg.rand_fps_hi > 0;
+        const int epw = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
         const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
-        hipLaunchKernelGGL(ftl_frames_group_kernel<4>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
-    } else {
-        const int epw = FTL_WAVE / 8;
-        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
-        hipLaunchKernelGGL(ftl_frames_group_kernel<8>, dim3((h->P.n_envs + epw - 1) / epw), dim3(FTL_WAVE), lds, (hipStream_t)stream, h->dP, call);
+        const dim3 grid((h->P.n_envs + epw - 1) / epw), block(FTL_WAVE);
+        hipStream_t s = (hipStream_t)stream;
+        if (h->P.R <= 4) {
+            if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<4, true>), grid, block, lds, s, h->dP, call);
+            else hipLaunchKernelGGL((ftl_frames_group_kernel<4, false>), grid, block, lds, s, h->dP, call);
+        } else {
+            if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<8, true>), grid, block, lds, s, h->dP, call);
+            else hipLaunchKernelGGL((ftl_frames_group_kernel<8, false>), grid, block, lds, s, h->dP, call);
+        }
     }
     if (h->P.cfg.n_lasers > 0) {
         bool expl = false;

@@ -424,7 +424,8 @@ __device__ __forceinline__ int g_cache_class(const ftl_config& c, const GCtx& E,
     return fast;
 }
 
-template <int G>
+// REG = the config has leader regimes or random_frames_per_step: compiled apart (their mere presence cost the common kernel 2 %)
+template <int G, bool REG>
 __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near, float4* s_bb, int& tick,
                                         double& reward, int& i0, int& i1, int& i2, const bool first) {
     const ftl_config& c = P.cfg;
@@ -475,7 +476,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     }
     // leader speed / acceleration regimes (ENV:1048-1058, 1143-1174); evaluated only while the leader is under way
     double lspeed = c.leader.max_speed + 0;
-    if (!E.leader_finished && (c.n_speed_regime >= 0 || c.n_acc_regime >= 0)) {
+    if (REG && !E.leader_finished && (c.n_speed_regime >= 0 || c.n_acc_regime >= 0)) {
         double speed = c.leader.max_speed, acceleration = 0;
         if (c.n_speed_regime >= 0) {
             int sel = -1;
@@ -1030,7 +1031,7 @@ __global__ void ftl_perm_identity_kernel(int32_t* perm, int n) { const int i = b
 #define FTL_FRAMESG_WPE 2
 #endif
 
-template <int G>
+template <int G, bool REG>
 __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
     using namespace ftl;
@@ -1087,14 +1088,14 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
 #ifdef FTL_ABLATE_FRAMES
         const int f_max = FTL_ABLATE_FRAMES;
 #else
-        const int f_max = P.cfg.rand_fps_hi > 0 ? P.cfg.rand_fps_hi - 1 : P.cfg.frames_per_step;
+        const int f_max = (REG && P.cfg.rand_fps_hi > 0) ? P.cfg.rand_fps_hi - 1 : P.cfg.frames_per_step;
 #endif
 #pragma nounroll
         for (int f = 0; f < f_max; f++) {
-            if (f < E.fps) g_frame<G>(P, E, L, near, bbl, tick, reward, i0, i1, i2, f == 0);
+            if (!REG || f < E.fps) g_frame<G, REG>(P, E, L, near, bbl, tick, reward, i0, i1, i2, f == 0);
             __syncthreads();          // an appended trajectory point is read by the other lanes of the group next frame
         }
-        if (P.cfg.rand_fps_hi > 0) E.fps = d_rand_frames(P.cfg, E.env, E.resets, E.step_count);      // ENV:939-940: the next step's frames
+        if (REG && P.cfg.rand_fps_hi > 0) E.fps = d_rand_frames(P.cfg, E.env, E.resets, E.step_count);      // ENV:939-940: the next step's frames
         if (E.valid && E.r == 0) {
             C.out.reward[E.env] = reward; C.out.done[E.env] = (uint8_t)E.done;
             C.out.status[3 * (size_t)E.env] = (uint8_t)i0; C.out.status[3 * (size_t)E.env + 1] = (uint8_t)i1; C.out.status[3 * (size_t)E.env + 2] = (uint8_t)i2;
