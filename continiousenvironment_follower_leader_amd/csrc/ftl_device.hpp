@@ -325,7 +325,7 @@ __device__ __forceinline__ bool hit_segment(float cx, float cy, double ex, doubl
 //   rays).  A hit is folded into the nearest squared distance of (ray, snapshot) with a 64-bit LDS atomic min
 //   (non-negative doubles order like their bit patterns).
 // Phase 4 (one RAY per lane): H minima -> the H output rows of the ray.
-// HM = compile-time number of history accumulators (5 covers every in-repo config, 8 is the ABI cap)
+// HM = compile-time number of history accumulators: 5, 8, 10 (the shipped training configs) or FTL_HMAX = 12
 // atan2 for the candidate-ray arc of phase 3 only: |error| <= 2e-5 rad (Abramowitz-Stegun 4.4.47 polynomial on [0,1] +
 // octant folding), two orders of magnitude inside the arc slack (>= 0.01 rad) that absorbs it.  Never used for a value
 // that reaches an output.
