@@ -34,6 +34,9 @@ struct ftl_handle {
     void* rg_mem;            // perm | bh | rank | keys | two key-total buffers (library-owned)
     int* rg_tot;             // [2][FTL_NKEYS]
     unsigned rg_parity, rg_launches, rg_every;
+    // optionally the slot groups are stepped as two interleaved halves on two streams (the caller's stream waits for the side
+    // stream): the ray kernel of one half fills the tail of the other half's frame kernel
+    hipStream_t side; hipEvent_t ev_fork, ev_join; bool split;
 };
 
 namespace {
@@ -97,6 +100,12 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     h->device = device;
     h->bound = false; h->have_scen = false; h->dP = nullptr; h->dirty = true;
     h->rg_mem = nullptr; h->rg_tot = nullptr; h->rg_parity = 0; h->rg_launches = 0;
+    h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
+    {   // measured: +9 % with random_frames_per_step (long frame kernels whose tails the other half's ray kernel fills), -1 % with a
+        // fixed 10 frames per step -- so it is on for the former only; FTL_SPLIT=0/1 overrides
+        const char* sp = getenv("FTL_SPLIT");
+        h->split = n_envs >= 8192 && (sp ? sp[0] == '1' : cfg->rand_fps_hi > 0);
+    }
     {   // the scatter pass reads one histogram row per block of 1024 envs: fine up to a few hundred blocks
         const char* off = getenv("FTL_NO_REGROUP");
         const char* ev = getenv("FTL_REGROUP_EVERY");      // tuning knob: rebuild the permutation every k-th launch (default 2)
@@ -148,9 +157,12 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
 
 void ftl_destroy(ftl_handle* h) {
     if (!h) return;
-    if (h->dP || h->rg_mem) (void)hipSetDevice(h->device);
+    if (h->dP || h->rg_mem || h->side) (void)hipSetDevice(h->device);
     if (h->dP) (void)hipFree(h->dP);
     if (h->rg_mem) (void)hipFree(h->rg_mem);
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
 }
 
@@ -228,35 +240,53 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
         h->dirty = false;
     }
-    // frame loop: G lanes per env (4 for <= 2 dynamic obstacles, else 8); configs with leader regimes or random frame counts
-    // use the instantiations that carry that code
-    {
+    if (h->split && !h->side) {
+        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+            return fail(FTL_E_DEVICE, "cannot create the side stream / events");
+    }
+    // one slot range: frame loop (G lanes per env: 4 for <= 2 dynamic obstacles, else 8; configs with leader regimes or random
+    // frame counts use the instantiations that carry that code), then the ray sensors of the same envs
+    // (the halves are interleaved wavefront by wavefront, so both see the same mix of the cost-sorted slots)
+    auto launch_range = [&](int part, int parts, hipStream_t s) {
+        const int epw0 = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
+        const int n_groups = (h->P.n_envs + epw0 - 1) / epw0;
+        const int my_groups = (n_groups - part + parts - 1) / parts;
+        FtlCall c2 = call; c2.part = part; c2.parts = parts; c2.epw = epw0;
+        const int count = my_groups * epw0;              // slots of this launch (the tail of the last group may be idle)
         const bool reg = h->P.cfg.n_speed_regime >= 0 || h->P.cfg.n_acc_regime >= 0 || h->P.cfg.rand_fps_hi > 0;
         const int epw = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
         const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
-        const dim3 grid((h->P.n_envs + epw - 1) / epw), block(FTL_WAVE);
-        hipStream_t s = (hipStream_t)stream;
+        const dim3 grid((count + epw - 1) / epw), block(FTL_WAVE);
         if (h->P.R <= 4) {
-            if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<4, true>), grid, block, lds, s, h->dP, call);
-            else hipLaunchKernelGGL((ftl_frames_group_kernel<4, false>), grid, block, lds, s, h->dP, call);
+            if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<4, true>), grid, block, lds, s, h->dP, c2);
+            else hipLaunchKernelGGL((ftl_frames_group_kernel<4, false>), grid, block, lds, s, h->dP, c2);
         } else {
-            if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<8, true>), grid, block, lds, s, h->dP, call);
-            else hipLaunchKernelGGL((ftl_frames_group_kernel<8, false>), grid, block, lds, s, h->dP, call);
+            if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<8, true>), grid, block, lds, s, h->dP, c2);
+            else hipLaunchKernelGGL((ftl_frames_group_kernel<8, false>), grid, block, lds, s, h->dP, c2);
         }
-    }
-    if (h->P.cfg.n_lasers > 0) {
-        bool expl = false;
-        for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0 || h->P.cfg.lasers[k].pad_sectors != 0;
-        const dim3 grid(h->P.n_envs), block(FTL_WAVE);
-        hipStream_t s = (hipStream_t)stream;
-        if (expl) {        // LeaderCorridor_lasers or pad_sectors somewhere in the config: the two instantiations that carry that code
-            if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, true>), grid, block, h->P.lds_rays, s, h->dP, call);
-            else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, true>), grid, block, h->P.lds_rays, s, h->dP, call);
-        } else if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, false>), grid, block, h->P.lds_rays, s, h->dP, call);
-        else if (h->P.hmax <= 8) hipLaunchKernelGGL((ftl_rays_kernel<8, false>), grid, block, h->P.lds_rays, s, h->dP, call);
-        else if (h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false>), grid, block, h->P.lds_rays, s, h->dP, call);   // the shipped training configs
-        else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, false>), grid, block, h->P.lds_rays, s, h->dP, call);
-    }
+        if (h->P.cfg.n_lasers > 0) {
+            bool expl = false;
+            for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0 || h->P.cfg.lasers[k].pad_sectors != 0;
+            const dim3 rgrid(count);
+            if (expl) {        // LeaderCorridor_lasers or pad_sectors somewhere in the config: the two instantiations that carry that code
+                if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+                else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+            } else if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+            else if (h->P.hmax <= 8) hipLaunchKernelGGL((ftl_rays_kernel<8, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+            else if (h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);   // the shipped training configs
+            else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+        }
+    };
+    if (h->split) {
+        (void)hipEventRecord(h->ev_fork, (hipStream_t)stream);              // everything the caller queued (actions, ...) happens first
+        (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+        launch_range(0, 2, (hipStream_t)stream);
+        launch_range(1, 2, h->side);
+        (void)hipEventRecord(h->ev_join, h->side);
+        (void)hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0);        // the caller's stream sees the whole step
+    } else launch_range(0, 1, (hipStream_t)stream);
     // the frame kernel left every env's cost class for its next step: rebuild the slot -> env map.  The classes are stable
     // from step to step unless the frame count is random, so every second launch is enough then.
     if (h->regroup && (h->P.cfg.rand_fps_hi > 0 || call.mode == 1 || (h->rg_launches++ % h->rg_every) == 0)) {

@@ -51,6 +51,8 @@ struct FtlCall {
     const double* action; const int32_t* scen_idx; const uint8_t* mask;
     ftl_outputs out;
     uint32_t flags; int32_t mode;      // mode 0 = step, 1 = reset
+    int32_t part, parts, epw;          // this launch covers the slot groups (epw consecutive slots = one frame-kernel wavefront)
+                                       // part, part + parts, part + 2*parts, ... of the slot -> env permutation
 };
 
 namespace ftl {
@@ -358,8 +360,10 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     using namespace ftl;
     const FtlDevParams& P = *Pp;
     const ftl_config& c = P.cfg;
-    const int env = blockIdx.x;
-    if (env >= P.n_envs) return;
+    // the ray kernel follows the frame kernel's slot -> env map: block b serves slot (b % epw) of this launch's (b / epw)-th group
+    const int gslot = ((int)(blockIdx.x / C.epw) * C.parts + C.part) * C.epw + (int)(blockIdx.x % C.epw);
+    if (gslot >= P.n_envs) return;
+    const int env = P.perm ? P.perm[gslot] : gslot;
     if (C.mode == 1 && C.mask && !C.mask[env]) return;
     const int lane = threadIdx.x;
 #ifdef FTL_PROFILE_RAYS

@@ -1041,7 +1041,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     E.slot = threadIdx.x / G; E.r = threadIdx.x % G;
     // Envs are not bound to wavefronts: slot -> env goes through the permutation that ftl_regroup_* rebuilt after the last
     // launch (envs with similar expected cost share a wavefront, expensive ones first); any permutation gives the same results.
-    const int gslot = blockIdx.x * EPW + E.slot;
+    const int gslot = ((int)blockIdx.x * C.parts + C.part) * EPW + E.slot;     // this launch's share of the slot groups
     E.valid = gslot < P.n_envs;
     E.env = E.valid ? (P.perm ? P.perm[gslot] : gslot) : P.n_envs - 1;       // idle groups shadow the last env (loads only; every store is guarded)
     int4* s_near = reinterpret_cast<int4*>(lds);
