@@ -190,8 +190,8 @@ def main():
                        "episodes_finished": float(metrics[0].item()), "env_error_flags": float(metrics[2].item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ftl_frames_group_kernel<4, %s> + ftl_rays_kernel<%d, false> (one step = both launches, same stream)"
-                                   % (("false", 5) if a.workload == "B" else ("true", 10)),
+                         "kernel": "ftl_frames_group_kernel<4, %s> + ftl_rays_kernel<%d, false, %s> (one step = both launches%s)"
+                                   % (("false", 5, "false", ", same stream") if a.workload == "B" else ("true", 10, "true", ", two interleaved halves on two streams")),
                          "kernel_ms": kernel_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP},
         }
         if world == 1 and not a.no_cpu_baseline and a.workload == "B":

@@ -270,13 +270,17 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
             bool expl = false;
             for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0 || h->P.cfg.lasers[k].pad_sectors != 0;
             const dim3 rgrid(count);
-            if (expl) {        // LeaderCorridor_lasers or pad_sectors somewhere in the config: the two instantiations that carry that code
-                if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-                else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-            } else if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-            else if (h->P.hmax <= 8) hipLaunchKernelGGL((ftl_rays_kernel<8, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-            else if (h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);   // the shipped training configs
-            else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+            if (parts > 1) {   // two-stream mode: the instantiations that map blocks to one half of the slot groups
+                if (!expl && h->P.hmax > 5 && h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+                else if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, true, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+                else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, true, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+            } else if (expl) {        // LeaderCorridor_lasers or pad_sectors somewhere in the config: the two instantiations that carry that code
+                if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, true, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+                else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, true, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+            } else if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+            else if (h->P.hmax <= 8) hipLaunchKernelGGL((ftl_rays_kernel<8, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+            else if (h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);   // the shipped training configs
+            else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
         }
     };
     if (h->split) {

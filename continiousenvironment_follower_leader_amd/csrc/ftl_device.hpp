@@ -354,16 +354,22 @@ __shared__ unsigned long long s_rcyc[16];
 
 // EXPL = the config uses one of the rarer sensor features -- rays at explicit angles (LeaderCorridor_lasers) or the pad_sectors
 // row layout: compiled apart so that the common kernels carry none of that code (it cost 3 % even when never executed)
-template <int HM, bool EXPL = false>
+// SPLIT = the launch covers one of the interleaved halves of the slot groups (two-stream mode) instead of all envs
+template <int HM, bool EXPL = false, bool SPLIT = false>
 __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
     using namespace ftl;
     const FtlDevParams& P = *Pp;
     const ftl_config& c = P.cfg;
-    // the ray kernel follows the frame kernel's slot -> env map: block b serves slot (b % epw) of this launch's (b / epw)-th group
-    const int gslot = ((int)(blockIdx.x / C.epw) * C.parts + C.part) * C.epw + (int)(blockIdx.x % C.epw);
-    if (gslot >= P.n_envs) return;
-    const int env = P.perm ? P.perm[gslot] : gslot;
+    // One launch for all envs: block b serves env b (any order will do).  A launch for one of `parts` interleaved halves must
+    // serve exactly the envs its frame kernel served: slot (b % epw) of this launch's (b / epw)-th group of the slot -> env map.
+    int env = blockIdx.x;
+    if (SPLIT) {
+        const int gslot = ((int)(blockIdx.x / C.epw) * C.parts + C.part) * C.epw + (int)(blockIdx.x % C.epw);
+        if (gslot >= P.n_envs) return;
+        env = P.perm ? P.perm[gslot] : gslot;
+    }
+    if (env >= P.n_envs) return;
     if (C.mode == 1 && C.mask && !C.mask[env]) return;
     const int lane = threadIdx.x;
 #ifdef FTL_PROFILE_RAYS
