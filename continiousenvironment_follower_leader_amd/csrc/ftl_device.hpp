@@ -354,6 +354,10 @@ __shared__ unsigned long long s_rcyc[16];
 
 // EXPL = the config uses one of the rarer sensor features -- rays at explicit angles (LeaderCorridor_lasers) or the pad_sectors
 // row layout: compiled apart so that the common kernels carry none of that code (it cost 3 % even when never executed)
+// The per-sensor loops run to the compile-time bound FTL_MAX_LASERS with the count as a guard: unrolled, the config fields they
+// read become loop-invariant scalar loads that the compiler hoists out of the chunk loops (the ray kernel got 5 % faster).
+#define FTL_FOR_LASERS(k) _Pragma("unroll") for (int k = 0; k < FTL_MAX_LASERS; k++) if (k < c.n_lasers)
+
 // SPLIT = the launch covers one of the interleaved halves of the slot groups (two-stream mode) instead of all envs
 template <int HM, bool EXPL = false, bool SPLIT = false>
 __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
 #pragma nounroll
     for (int which = 0; which < 2; which++) {
         int n_sens = 0; float lmax = 0.0f;
-        for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) { n_sens++; lmax = fmaxf(lmax, (float)c.lasers[k].length); }
+        FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) { n_sens++; lmax = fmaxf(lmax, (float)c.lasers[k].length); }
         if (n_sens == 0) continue;
         if (!((scan_ok >> which) & 1)) {       // sensors.py:893/962: the reference raises UnboundLocalError here
             for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which)
@@ -516,10 +520,10 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         // of 12 rays alone would leave 52 lanes idle through the f64 sin/cos)
         {
             int n_rays = 0;
-            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) n_rays += c.lasers[k].count;
+            FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) n_rays += c.lasers[k].count;
             for (int g = lane; g < n_rays; g += FTL_WAVE) {
                 int i = g; double len = 0, aoff = 0, period = 0; bool found = false; int kk = 0;
-                for (int k = 0; k < c.n_lasers; k++) {
+                FTL_FOR_LASERS(k) {
                     if (c.lasers[k].after_tracker != which) continue;
                     const int N = c.lasers[k].count;
                     if (!found && i < N) { found = true; kk = k; len = c.lasers[k].length; aoff = c.lasers[k].angle_offset; period = 360.0 / (double)N; }
@@ -546,7 +550,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         {
             // flattened work list: for every sensor of the group the table entries of the classes it reacts to
             int n_items = 0;
-            for (int k = 0; k < c.n_lasers; k++) {
+            FTL_FOR_LASERS(k) {
                 if (c.lasers[k].after_tracker != which) continue;
                 const int ro = c.lasers[k].react_obstacles;
                 if (ro == 1 || ro == 2) n_items += 4 * s_cnt[SEG_STATIC];      // 4 edges per rect
@@ -560,7 +564,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 int m = -1, mq = 0, N = 1, rbase = 0; float lenf = 0.0f, phi0 = 0.0f; bool expl = false;
                 {
                     int rem = w, rb = 0;
-                    for (int k = 0; k < c.n_lasers; k++) {
+                    FTL_FOR_LASERS(k) {
                         if (c.lasers[k].after_tracker != which) continue;
                         const int ro = c.lasers[k].react_obstacles;
                         const bool on[SEG_CLASSES] = { ro == 1 || ro == 2, ro == 1 || ro == 3, c.lasers[k].react_corridor != 0, c.lasers[k].react_green != 0 };
@@ -669,7 +673,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         {
             float* pol = C.out.policy_obs ? C.out.policy_obs + (size_t)env * P.pol_h * P.pol_width : nullptr;
             bool any_pad = false;
-            for (int k = 0; k < c.n_lasers; k++) if (EXPL && c.lasers[k].after_tracker == which && c.lasers[k].pad_sectors) {
+            FTL_FOR_LASERS(k) if (EXPL && c.lasers[k].after_tracker == which && c.lasers[k].pad_sectors) {
                 any_pad = true;
                 const int tot = c.lasers[k].history * 4 * c.lasers[k].count;
                 for (int i = lane; i < tot; i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = 0.0f;
@@ -681,12 +685,12 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             if (any_pad) __syncthreads();
             // one (ray, age) pair per lane over all sensors of the group: pair p of sensor k = age * N_k + ray
             int n_pairs = 0;
-            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) n_pairs += c.lasers[k].count * c.lasers[k].history;
+            FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) n_pairs += c.lasers[k].count * c.lasers[k].history;
             for (int p = lane; p < n_pairs; p += FTL_WAVE) {
                 int q = p, N = 1, H = 1, ooff = 0, rb = 0, poff = 0; bool pad = false, found = false; float flen = 1.0f;
                 {
                     int rbase = 0;
-                    for (int k = 0; k < c.n_lasers; k++) {
+                    FTL_FOR_LASERS(k) {
                         if (c.lasers[k].after_tracker != which) continue;
                         const int np = c.lasers[k].count * c.lasers[k].history;
                         if (!found && q < np) {
