@@ -19,13 +19,16 @@ LEADER = ("moving", "crash", "finished")
 
 FTL_ERR_TRAJ_OVERFLOW, FTL_ERR_CORR_OVERFLOW, FTL_ERR_EMPTY_CORRIDOR, FTL_ERR_TRACKER_SEED = 1, 2, 4, 8
 FTL_STEP_AUTO_RESET = 1
+FTL_N_METRICS = 8
+FTL_METRICS_CLEAR = 1
+(M_EPISODES, M_RETURN_SUM, M_FRAMES_SUM, M_SUCCESS, M_CRASH, M_LOW_REWARD, M_TOO_FAR, M_TIMEOUT) = range(8)
 
 # env_int indices
 (EI_SCEN, EI_TARGET_ID, EI_LEADER_FINISHED, EI_DONE, EI_CRASH, EI_IN_BOX, EI_ON_TRACE, EI_TOO_CLOSE,
  EI_STEP_COUNT, EI_FINISH_TIMER, EI_TRAJ_LEN, EI_TRK_COUNTER, EI_CORR_LO, EI_CORR_HI, EI_SEED_END,
  EI_SNAP_COUNT, EI_DYN_INDEX0, EI_DYN_INDEX1, EI_DYN_INDEX2, EI_DYN_INDEX3, EI_ERROR, EI_EPISODES,
  EI_GREEN_COUNT, EI_GREEN_LEN, EI_SCAN_OK, EI_SNAP_HEAD, EI_HINT, EI_GREEN_TINY, EI_RESETS, EI_ACC_CONSUMED,
- EI_HINT_X, EI_HINT_Y, EI_CLR_GREEN, EI_CLR_ALL, EI_FPS, EI_COUNT) = range(36)
+ EI_HINT_X, EI_HINT_Y, EI_CLR_GREEN, EI_CLR_ALL, EI_FPS, EI_ERROR_STICKY, EI_COUNT) = range(37)
 ED_ACC_PENALTY, ED_OVERALL_REWARD, ED_SPARE0, ED_SPARE1, ED_BEAR_POINTS = range(5)
 ED_GREEN_W = ED_BEAR_POINTS + 2 * FTL_MAX_BEARS
 ED_CUR_MULT, ED_CUR_ACC, ED_CUM_SPEED = ED_GREEN_W + 1, ED_GREEN_W + 2, ED_GREEN_W + 3
@@ -49,7 +52,7 @@ class RobotParams(C.Structure):
 class LaserCfg(C.Structure):
     _fields_ = [("count", C.c_int32), ("react_corridor", C.c_int32), ("react_green", C.c_int32),
                 ("react_obstacles", C.c_int32), ("history", C.c_int32), ("after_tracker", C.c_int32),
-                ("out_offset", C.c_int32), ("pad_sectors", C.c_int32), ("lenient", C.c_int32), ("_pad", C.c_int32),
+                ("out_offset", C.c_int32), ("pad_sectors", C.c_int32), ("lenient", C.c_int32), ("in_policy_obs", C.c_int32),
                 ("length", C.c_double), ("angle_offset", C.c_double),
                 ("explicit_angles", C.c_int32), ("_pad2", C.c_int32), ("ray_angles", C.c_double * 8)]
 

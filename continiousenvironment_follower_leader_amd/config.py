@@ -22,6 +22,8 @@ DEPRECATED_SENSOR_CLASSES = {
     "GreenBoxBorderSensor": (ValueError, "To use it, you need to uncomment the call self._get_green_zone_border_points(). Commented out because it slows down the simulation"),
     "LeaderObstacles_lasers": (ValueError, "Deprecated class, use LeaderCorridor_lasers_v2 with flags insteadreact_to_safe_corridor=False and react_to_green_zone=False"),
     "Leader_Dyn_Obstacles_lasers": (ValueError, "Deprecated class, use LeaderCorridor_lasers_v2 with flags insteadreact_to_safe_corridor=False and react_to_green_zone=False, react_to_obstacles='dynamic'"),
+    # (constructs in the reference; its scan raises at the first use_sensors, i.e. inside the first reset(), SEN:993)
+    "LeaderCorridor_Prev_lasers_v3": (ValueError, "The sensor ignores all points inside the corridor, including obstacles, this is an error"),
     "LaserPrevSensor": (TypeError, "This is an obsolete class, you should use LeaderCorridor_Prev_lasers_v2 with flags insteadreact_to_safe_corridor=False and react_to_green_zone=False, react_to_obstacles=True and first_laser_angle_offset=0"),
 }
 KNOWN_SENSOR_CLASSES = ("LaserSensor", "LeaderPositionsTracker", "LeaderPositionsTracker_v2",
@@ -47,6 +49,7 @@ class LaserSpec:
     out_offset: int = 0
     lenient: bool = False       # LeaderCorridor_lasers_v2: flat [count] observation, no error on a short corridor
     ray_angles: tuple = None    # LeaderCorridor_lasers: explicit ray directions relative to the heading, deg
+    in_policy_obs: bool = False  # one of the classes ContinuousObserveModifier_sensorPrev concatenates (wrappers.py:204, 214)
 
     @property
     def width(self):            # row width of the sensor's output block (SEN:932-958)
@@ -290,7 +293,8 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
                                     react_obstacles=_react_code(spec.get("react_to_obstacles", False)),
                                     history=int(hist),
                                     angle_offset=float(spec.get("first_laser_angle_offset", -45)),
-                                    after_tracker=seen_tracker, pad_sectors=bool(spec.get("pad_sectors", True))))
+                                    after_tracker=seen_tracker, pad_sectors=bool(spec.get("pad_sectors", True)),
+                                    in_policy_obs=True))
     if lasers and not c.has_tracker:
         raise NotImplementedError("ray sensors need LeaderPositionsTracker_v2 (reference: NameError on "
                                   "`leader_corridor`, CLS:280)")
@@ -306,6 +310,7 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
         lc.angle_offset, lc.after_tracker, lc.out_offset = l.angle_offset, int(l.after_tracker), off
         lc.pad_sectors = int(l.pad_sectors)
         lc.lenient = int(l.lenient)
+        lc.in_policy_obs = int(l.in_policy_obs)
         lc.explicit_angles = int(l.ray_angles is not None)
         for i, a in enumerate(l.ray_angles or ()):
             lc.ray_angles[i] = a

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include <cstdlib>
 
@@ -19,6 +20,7 @@ thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct Field { const char* name; size_t offset, per_env; int dtype; };
+constexpr int FTL_N_FIELDS = 12;
 
 }  // namespace
 
@@ -28,7 +30,11 @@ struct ftl_handle {
     bool dirty;
     int device;
     size_t state_bytes;
-    Field fields[11];
+    Field fields[FTL_N_FIELDS];
+    void* mt_mem;            // partial sums of ftl_episode_metrics (library-owned)
+    bool timing;             // ftl_kernel_timing: events around every launch of a step
+    std::vector<hipEvent_t> tev;   // 4 per timed step: before frames | after frames | after rays | after regroup
+    size_t tev_used;
     bool bound, have_scen;
     bool regroup;            // envs are regrouped by expected cost after every launch (off: FTL_NO_REGROUP=1, or too many envs)
     void* rg_mem;            // perm | bh | rank | keys | two key-total buffers (library-owned)
@@ -99,7 +105,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     h->P.cfg = *cfg;
     h->device = device;
     h->bound = false; h->have_scen = false; h->dP = nullptr; h->dirty = true;
-    h->rg_mem = nullptr; h->rg_tot = nullptr; h->rg_parity = 0; h->rg_launches = 0;
+    h->rg_mem = nullptr; h->rg_tot = nullptr; h->rg_parity = 0; h->rg_launches = 0; h->mt_mem = nullptr; h->timing = false; h->tev_used = 0;
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
     {   // measured: +9 % with random_frames_per_step (long frame kernels whose tails the other half's ray kernel fills), -1 % with a
         // fixed 10 frames per step -- so it is on for the former only; FTL_SPLIT=0/1 overrides
@@ -124,21 +130,27 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
     if (hmax * (P.R - 1) > FTL_WAVE) { delete h; return fail(FTL_E_INVALID, "max_prev_obs x (1 + bears) exceeds one wavefront of snapshot rects"); }
-    {   // row width / common history of the fused sensorPrev output
-        int w = 0, hcommon = cfg->n_lasers ? cfg->lasers[0].history : 0;
-        for (int k = 0; k < cfg->n_lasers; k++) { P.pol_off[k] = w; w += cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1); if (cfg->lasers[k].history != hcommon) hcommon = -1; }
+    {   // row width / common history of the fused sensorPrev output: the sensors wrappers.py:204, 214 select (in_policy_obs), in dict order
+        int w = 0, hcommon = 0;
+        for (int k = 0; k < cfg->n_lasers; k++) {
+            P.pol_off[k] = -1;
+            if (!cfg->lasers[k].in_policy_obs) continue;
+            P.pol_off[k] = w; w += cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1);
+            if (hcommon == 0) hcommon = cfg->lasers[k].history;
+            else if (cfg->lasers[k].history != hcommon) hcommon = -1;
+        }
         P.pol_width = w; P.pol_h = hcommon;
     }
     // state layout: one region per field, [n_envs][per_env], 256-byte aligned
     const size_t n = (size_t)n_envs;
-    struct { const char* name; size_t per_env; int dtype; size_t esz; } spec[11] = {
+    struct { const char* name; size_t per_env; int dtype; size_t esz; } spec[FTL_N_FIELDS] = {
         {"rb_pos", (size_t)P.R * 2, 1, 4}, {"rb_dbl", (size_t)P.R * FTL_RD_COUNT, 2, 8}, {"rb_int", (size_t)P.R * FTL_RI_COUNT, 0, 4},
         {"env_int", FTL_EI_COUNT, 0, 4}, {"env_dbl", FTL_ED_COUNT, 2, 8}, {"traj", (size_t)cfg->traj_cap * 2, 1, 4},
         {"hist", (size_t)cfg->corr_cap * 2, 2, 8}, {"corr", (size_t)cfg->corr_cap * 4, 2, 8},
         {"snap_rects", (size_t)hmax * (P.R - 1) * 4, 0, 4}, {"snap_win", (size_t)hmax * 4, 0, 4},
-        {"traj_bb", (size_t)(cfg->traj_cap / FTL_TRAJ_BLOCK) * 4, 1, 4}};
+        {"traj_bb", (size_t)(cfg->traj_cap / FTL_TRAJ_BLOCK) * 4, 1, 4}, {"ep_stats", FTL_N_METRICS, 2, 8}};
     size_t cur = 0;
-    for (int i = 0; i < 11; i++) {
+    for (int i = 0; i < FTL_N_FIELDS; i++) {
         cur = align_up(cur, 256);
         h->fields[i] = Field{spec[i].name, cur, spec[i].per_env, spec[i].dtype};
         cur += spec[i].per_env * spec[i].esz * n;
@@ -157,8 +169,10 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
 
 void ftl_destroy(ftl_handle* h) {
     if (!h) return;
-    if (h->dP || h->rg_mem || h->side) (void)hipSetDevice(h->device);
+    if (h->dP || h->rg_mem || h->side || h->mt_mem) (void)hipSetDevice(h->device);
     if (h->dP) (void)hipFree(h->dP);
+    if (h->mt_mem) (void)hipFree(h->mt_mem);
+    for (hipEvent_t ev : h->tev) (void)hipEventDestroy(ev);
     if (h->rg_mem) (void)hipFree(h->rg_mem);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -178,7 +192,7 @@ size_t ftl_state_bytes(const ftl_handle* h) { return h ? h->state_bytes : 0; }
 
 int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype) {
     if (!h || !name) return fail(FTL_E_INVALID, "null argument");
-    for (int i = 0; i < 11; i++)
+    for (int i = 0; i < FTL_N_FIELDS; i++)
         if (!strcmp(h->fields[i].name, name)) {
             if (offset) *offset = h->fields[i].offset;
             if (per_env) *per_env = h->fields[i].per_env;
@@ -198,7 +212,7 @@ int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes) {
     P.env_int = (int32_t*)(b + h->fields[3].offset); P.env_dbl = (double*)(b + h->fields[4].offset); P.traj = (float*)(b + h->fields[5].offset);
     P.hist = (double*)(b + h->fields[6].offset); P.corr = (double*)(b + h->fields[7].offset);
     P.snap_rects = (int32_t*)(b + h->fields[8].offset); P.snap_win = (int32_t*)(b + h->fields[9].offset);
-    P.traj_bb = (float*)(b + h->fields[10].offset);
+    P.traj_bb = (float*)(b + h->fields[10].offset); P.ep_stats = (double*)(b + h->fields[11].offset);
     h->bound = true; h->dirty = true;
     return FTL_OK;
 }
@@ -214,14 +228,25 @@ int ftl_load_scenarios(ftl_handle* h, const ftl_scenarios* pool) {
     return FTL_OK;
 }
 
-static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
-    hipError_t e = hipSetDevice(h->device);
-    if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+// device copy of the frozen parameters: (re)uploaded only after bind_state / load_scenarios, never on the steady-state step path
+static int sync_params(ftl_handle* h) {
+    hipError_t e;
     if (!h->dP) {
         e = hipMalloc((void**)&h->dP, sizeof(FtlDevParams));
         if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMalloc(params): ") + hipGetErrorString(e));
         h->dirty = true;
     }
+    if (h->dirty) {
+        e = hipMemcpy(h->dP, &h->P, sizeof(FtlDevParams), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
+        h->dirty = false;
+    }
+    return FTL_OK;
+}
+
+static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
     if (h->regroup && !h->rg_mem) {
         const size_t n = (size_t)h->P.n_envs, nb = (n + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK;
         const size_t o_bh = align_up(n * 4, 256), o_rank = o_bh + align_up(nb * FTL_NKEYS * 4, 256), o_keys = o_rank + align_up(n * 2, 256), o_tot = o_keys + align_up(n, 256);
@@ -235,11 +260,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         hipLaunchKernelGGL(ftl::ftl_perm_identity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->P.perm, (int)n);
         h->dirty = true;
     }
-    if (h->dirty) {   // only after bind_state / load_scenarios, never on the steady-state step path
-        e = hipMemcpy(h->dP, &h->P, sizeof(FtlDevParams), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
-        h->dirty = false;
-    }
+    { int rc = sync_params(h); if (rc) return rc; }
     if (h->split && !h->side) {
         if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -249,6 +270,12 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
     // one slot range: frame loop (G lanes per env: 4 for <= 2 dynamic obstacles, else 8; configs with leader regimes or random
     // frame counts use the instantiations that carry that code), then the ray sensors of the same envs
     // (the halves are interleaved wavefront by wavefront, so both see the same mix of the cost-sorted slots)
+    // optional per-kernel timing (ftl_kernel_timing): up to 512 steps of 4 events each, single-stream mode only
+    hipEvent_t* tev = nullptr;
+    if (h->timing && !h->split && call.mode == 0 && h->tev_used + 4 <= 4 * 512) {
+        while (h->tev.size() < h->tev_used + 4) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return fail(FTL_E_DEVICE, "hipEventCreate"); h->tev.push_back(ev); }
+        tev = h->tev.data() + h->tev_used; h->tev_used += 4;
+    }
     auto launch_range = [&](int part, int parts, hipStream_t s) {
         const int epw0 = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
         const int n_groups = (h->P.n_envs + epw0 - 1) / epw0;
@@ -259,6 +286,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         const int epw = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
         const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
         const dim3 grid((count + epw - 1) / epw), block(FTL_WAVE);
+        if (tev) (void)hipEventRecord(tev[0], s);
         if (h->P.R <= 4) {
             if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<4, true>), grid, block, lds, s, h->dP, c2);
             else hipLaunchKernelGGL((ftl_frames_group_kernel<4, false>), grid, block, lds, s, h->dP, c2);
@@ -266,6 +294,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
             if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<8, true>), grid, block, lds, s, h->dP, c2);
             else hipLaunchKernelGGL((ftl_frames_group_kernel<8, false>), grid, block, lds, s, h->dP, c2);
         }
+        if (tev) (void)hipEventRecord(tev[1], s);
         if (h->P.cfg.n_lasers > 0) {
             bool expl = false;
             for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0 || h->P.cfg.lasers[k].pad_sectors != 0;
@@ -282,6 +311,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
             else if (h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);   // the shipped training configs
             else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
         }
+        if (tev) (void)hipEventRecord(tev[2], s);
     };
     if (h->split) {
         (void)hipEventRecord(h->ev_fork, (hipStream_t)stream);              // everything the caller queued (actions, ...) happens first
@@ -300,6 +330,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         hipLaunchKernelGGL(ftl::ftl_regroup_count_kernel, dim3(nb), dim3(FTL_RG_BLOCK), 0, (hipStream_t)stream, h->dP, tot);
         hipLaunchKernelGGL(ftl::ftl_regroup_scatter_kernel, dim3(nb), dim3(FTL_RG_BLOCK), 0, (hipStream_t)stream, h->dP, (const int*)tot, tot_next);
     }
+    if (tev) (void)hipEventRecord(tev[3], (hipStream_t)stream);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
     return FTL_OK;
@@ -331,6 +362,54 @@ int ftl_step(ftl_handle* h, const double* action, const ftl_outputs* out, uint32
     if (out->policy_obs && h->P.pol_h <= 0) return fail(FTL_E_INVALID, "policy_obs needs the same max_prev_obs on every ray sensor");
     FtlCall call; call.mode = 0; call.action = action; call.out = *out; call.flags = flags; call.scen_idx = nullptr; call.mask = nullptr;
     return launch(h, call, stream);
+}
+
+int ftl_kernel_timing(ftl_handle* h, int32_t enable) {
+    if (!h) return fail(FTL_E_INVALID, "null argument");
+    if (enable && h->split) return fail(FTL_E_UNSUPPORTED, "per-kernel timing is not available in the two-stream mode");
+    h->timing = enable != 0; h->tev_used = 0;
+    return FTL_OK;
+}
+
+int ftl_kernel_times(ftl_handle* h, double* ms, int32_t* n_steps) {
+    if (!h || !ms || !n_steps) return fail(FTL_E_INVALID, "null argument");
+    if (h->split) return fail(FTL_E_UNSUPPORTED, "per-kernel timing is not available in the two-stream mode");
+    ms[0] = ms[1] = ms[2] = 0.0; *n_steps = 0;
+    if (h->tev_used == 0) return FTL_OK;
+    (void)hipSetDevice(h->device);
+    hipError_t e = hipEventSynchronize(h->tev[h->tev_used - 1]);
+    if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+    for (size_t i = 0; i + 4 <= h->tev_used; i += 4) {
+        for (int k = 0; k < 3; k++) {
+            float t = 0.0f;
+            e = hipEventElapsedTime(&t, h->tev[i + k], h->tev[i + k + 1]);
+            if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipEventElapsedTime: ") + hipGetErrorString(e));
+            ms[k] += (double)t;
+        }
+        *n_steps += 1;
+    }
+    h->tev_used = 0;
+    return FTL_OK;
+}
+
+int ftl_episode_metrics(ftl_handle* h, double* dev_metrics, int32_t* dev_errors, uint32_t flags, void* stream) {
+    if (!h || !dev_metrics) return fail(FTL_E_INVALID, "null argument");
+    if (!h->bound) return fail(FTL_E_STATE, "ftl_bind_state has not been called");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    const int nb = (h->P.n_envs + FTL_MT_BLOCK - 1) / FTL_MT_BLOCK;
+    const size_t o_err = align_up((size_t)nb * FTL_N_METRICS * sizeof(double), 256);
+    if (!h->mt_mem) {
+        e = hipMalloc(&h->mt_mem, o_err + (size_t)nb * 2 * sizeof(int));
+        if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipMalloc(metrics): ") + hipGetErrorString(e));
+    }
+    { int rc = sync_params(h); if (rc) return rc; }
+    double* part = (double*)h->mt_mem; int* epart = (int*)((char*)h->mt_mem + o_err);
+    hipLaunchKernelGGL(ftl::ftl_metrics_partial_kernel, dim3((unsigned)nb), dim3(FTL_MT_THREADS), 0, (hipStream_t)stream, h->dP, part, epart, (flags & FTL_METRICS_CLEAR) ? 1 : 0);
+    hipLaunchKernelGGL(ftl::ftl_metrics_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)part, (const int*)epart, nb, dev_metrics, dev_errors);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+    return FTL_OK;
 }
 
 }  // extern "C"

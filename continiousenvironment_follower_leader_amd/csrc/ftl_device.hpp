@@ -36,11 +36,12 @@
 struct FtlDevParams {
     ftl_config cfg;
     int32_t n_envs, R, lasers_len, total_rays, hmax, lds_rays;
-    int32_t pol_off[FTL_MAX_LASERS], pol_width, pol_h;   // fused sensorPrev output: column offset per sensor, row width, common history
+    int32_t pol_off[FTL_MAX_LASERS], pol_width, pol_h;   // fused sensorPrev output: column offset per sensor (-1: not part of it), row width, common history
     // per-env state (views into the caller-owned state buffer), all [n_envs][...]
     float* rb_pos; double* rb_dbl; int32_t* rb_int; int32_t* env_int; double* env_dbl;
     float* traj; double* hist; double* corr; int32_t* snap_rects; int32_t* snap_win;
     float* traj_bb;                   // [n_envs][traj_cap / FTL_TRAJ_BLOCK][4]: xmin, ymin, xmax, ymax of each block of trajectory points
+    double* ep_stats;                 // [n_envs][FTL_N_METRICS]: metrics of the episodes that ended in this env slot (include/ftl.h)
     // env regrouping (library-owned; null = envs stay bound to their wavefronts): slot -> env, cost class of the next step,
     // rank inside the block histogram, per-block key histograms
     int32_t* perm; uint8_t* keys; uint16_t* rank; int32_t* bh;
@@ -433,8 +434,14 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) { n_sens++; lmax = fmaxf(lmax, (float)c.lasers[k].length); }
         if (n_sens == 0) continue;
         if (!((scan_ok >> which) & 1)) {       // sensors.py:893/962: the reference raises UnboundLocalError here
-            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which)
-                for (int i = lane; i < c.lasers[k].history * c.lasers[k].count * (c.lasers[k].pad_sectors ? 4 : 1); i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = (float)c.lasers[k].length;
+            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) {
+                const int Wd = c.lasers[k].count * (c.lasers[k].pad_sectors ? 4 : 1);
+                for (int i = lane; i < c.lasers[k].history * Wd; i += FTL_WAVE) {
+                    out_base[c.lasers[k].out_offset + i] = (float)c.lasers[k].length;
+                    if (C.out.policy_obs && P.pol_off[k] >= 0)       // clip(length / length, 0, 1)
+                        C.out.policy_obs[(size_t)env * P.pol_h * P.pol_width + (i / Wd) * P.pol_width + P.pol_off[k] + (i % Wd)] = 1.0f;
+                }
+            }
             continue;
         }
         // corridor windows of the valid snapshots as this group of sensors saw them; age a = 0 newest
@@ -677,7 +684,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 any_pad = true;
                 const int tot = c.lasers[k].history * 4 * c.lasers[k].count;
                 for (int i = lane; i < tot; i += FTL_WAVE) out_base[c.lasers[k].out_offset + i] = 0.0f;
-                if (pol) for (int i = lane; i < tot; i += FTL_WAVE) {
+                if (pol && P.pol_off[k] >= 0) for (int i = lane; i < tot; i += FTL_WAVE) {
                     int row = i / (4 * c.lasers[k].count), col = i - row * 4 * c.lasers[k].count;
                     pol[row * P.pol_width + P.pol_off[k] + col] = 0.0f;
                 }
@@ -715,7 +722,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 const double v = (a2 < nsnap && bb != kInfBits) ? sqrt(__longlong_as_double((long long)bb)) : s_miss[rb + i];
                 const float vf = (float)v;
                 out_base[ooff + (H - 1 - a2) * Wd + col] = vf;
-                if (pol) pol[(H - 1 - a2) * P.pol_width + poff + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
+                if (pol && poff >= 0) pol[(H - 1 - a2) * P.pol_width + poff + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
             }
         }
         FTL_RTIC(6);

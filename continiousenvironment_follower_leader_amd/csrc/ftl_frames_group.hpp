@@ -98,6 +98,7 @@ struct GCtx {
     int scen, cur_target_id, leader_finished, done, crash, is_in_box, is_on_trace, too_close;
     int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
     int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint, green_tiny, resets, acc_consumed;
+    int err_acc;         // error bits of episodes that ended inside this launch (g_reset clears `error`): OR-ed into FTL_EI_ERROR_STICKY
     int n_search;        // frames of this step in which this env needed a trajectory search (regrouping key only)
     int fps;             // frames of this step: cfg.frames_per_step, or the env's last draw under random_frames_per_step
     double acc_penalty, overall_reward, cur_tx, cur_ty;
@@ -160,6 +161,8 @@ __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
         ed[FTL_ED_CUR_MULT] = E.cur_mult; ed[FTL_ED_CUR_ACC] = E.cur_acc; ed[FTL_ED_CUM_SPEED] = E.cum_speed;
         ed[FTL_ED_ACC_PENALTY] = E.acc_penalty; ed[FTL_ED_OVERALL_REWARD] = E.overall_reward;
         ed[FTL_ED_SPARE0] = E.cur_tx; ed[FTL_ED_SPARE1] = E.cur_ty; ed[FTL_ED_GREEN_W] = E.green_w;
+        // the sticky error word is only ever touched when something went wrong (no load / store on the clean path)
+        if ((E.err_acc | E.error) != 0) atomicOr(&ei[FTL_EI_ERROR_STICKY], E.err_acc | E.error);
     }
     if (E.r < P.R) {
         size_t ro = (size_t)E.env * P.R + E.r;
@@ -1025,6 +1028,50 @@ __global__ void __launch_bounds__(FTL_RG_BLOCK) ftl_regroup_scatter_kernel(const
 }
 __global__ void ftl_perm_identity_kernel(int32_t* perm, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) perm[i] = i; }
 
+// ---- episode metrics (include/ftl.h ftl_episode_metrics): fixed-order sum of the per-env "ep_stats" records ---------------------
+// pass 1: block b sums envs [b*FTL_MT_BLOCK, (b+1)*FTL_MT_BLOCK) -- every thread walks its envs in index order, then a fixed
+// tree over the threads; pass 2: one block adds the partial vectors in block order.  No atomics: the result is bit-reproducible.
+#define FTL_MT_THREADS 256
+#define FTL_MT_BLOCK 4096
+__global__ void __launch_bounds__(FTL_MT_THREADS) ftl_metrics_partial_kernel(const FtlDevParams* __restrict__ Pp, double* __restrict__ part, int* __restrict__ epart, int clear) {
+    const FtlDevParams& P = *Pp;
+    __shared__ double sm[FTL_MT_THREADS][FTL_N_METRICS + 1];
+    __shared__ int se[FTL_MT_THREADS][2];
+    const int t = threadIdx.x;
+    double acc[FTL_N_METRICS];
+#pragma unroll
+    for (int k = 0; k < FTL_N_METRICS; k++) acc[k] = 0.0;
+    int ecount = 0, ebits = 0;
+    const int e0 = blockIdx.x * FTL_MT_BLOCK, e1 = min(e0 + FTL_MT_BLOCK, P.n_envs);
+    for (int e = e0 + t; e < e1; e += FTL_MT_THREADS) {
+        double* st = P.ep_stats + (size_t)e * FTL_N_METRICS;
+#pragma unroll
+        for (int k = 0; k < FTL_N_METRICS; k++) { acc[k] += st[k]; if (clear) st[k] = 0.0; }
+        int* sticky = P.env_int + (size_t)e * FTL_EI_COUNT + FTL_EI_ERROR_STICKY;
+        const int b = *sticky;
+        if (b) { ecount += 1; ebits |= b; if (clear) *sticky = 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < FTL_N_METRICS; k++) sm[t][k] = acc[k];
+    se[t][0] = ecount; se[t][1] = ebits;
+    __syncthreads();
+    for (int off = FTL_MT_THREADS / 2; off >= 1; off >>= 1) {
+        if (t < off) {
+#pragma unroll
+            for (int k = 0; k < FTL_N_METRICS; k++) sm[t][k] += sm[t + off][k];
+            se[t][0] += se[t + off][0]; se[t][1] |= se[t + off][1];
+        }
+        __syncthreads();
+    }
+    if (t < FTL_N_METRICS) part[blockIdx.x * FTL_N_METRICS + t] = sm[0][t];
+    if (t < 2) epart[blockIdx.x * 2 + t] = se[0][t];
+}
+__global__ void ftl_metrics_final_kernel(const double* __restrict__ part, const int* __restrict__ epart, int nb, double* __restrict__ out, int* __restrict__ eout) {
+    const int t = threadIdx.x;
+    if (t < FTL_N_METRICS) { double s = 0.0; for (int b = 0; b < nb; b++) s += part[b * FTL_N_METRICS + t]; out[t] = s; }
+    if (eout && t == FTL_N_METRICS) { int n = 0, bits = 0; for (int b = 0; b < nb; b++) { n += epart[2 * b]; bits |= epart[2 * b + 1]; } eout[0] = n; eout[1] = bits; }
+}
+
 }  // namespace ftl
 
 #ifndef FTL_FRAMESG_WPE
@@ -1046,7 +1093,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     E.env = E.valid ? (P.perm ? P.perm[gslot] : gslot) : P.n_envs - 1;       // idle groups shadow the last env (loads only; every store is guarded)
     int4* s_near = reinterpret_cast<int4*>(lds);
     int* s_cnt = reinterpret_cast<int*>(lds + (size_t)EPW * P.cfg.n_static * 16);
-    E.scan_ok = 0; E.near_cnt = 0; E.n_search = 0;
+    E.scan_ok = 0; E.near_cnt = 0; E.n_search = 0; E.err_acc = 0;
     const Limits L = lane_limits(P.cfg, E.r);
 #ifdef FTL_PROFILE_PATHS
     if (threadIdx.x < 16) s_cyc[threadIdx.x] = 0;
@@ -1057,6 +1104,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     if (C.mode == 1) {                                   // reset(): ENV:434-543
         if (C.mask && !C.mask[E.env]) E.valid = false;
         g_load<G>(P, E);                                 // keeps the state of masked-out envs intact (nothing is stored for them)
+        if (E.valid) E.err_acc |= E.error;               // the episode being replaced may have raised error bits: they stay in the sticky word
         g_reset<G>(P, E, E.valid ? C.scen_idx[E.env] : E.scen, E.valid);
         if (E.valid && E.r == 0) {
             C.out.reward[E.env] = 0.0; C.out.done[E.env] = (uint8_t)E.done;
@@ -1065,6 +1113,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         __syncthreads();
     } else {                                             // step(action): ENV:908-945
         g_load<G>(P, E);
+        const int done0 = E.done;
         FTL_TIC(4);
         // One memory round trip for everything the frames need besides the state: the action and the scenario's static rects
         // (culled into the near list).
@@ -1101,12 +1150,24 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
             C.out.status[3 * (size_t)E.env] = (uint8_t)i0; C.out.status[3 * (size_t)E.env + 1] = (uint8_t)i1; C.out.status[3 * (size_t)E.env + 2] = (uint8_t)i2;
         }
         FTL_TIC(9);
+        // Episode metrics: the reference reports overall_reward / step_count when done is raised (ENV:941-944).
+        // The record of a finishing episode goes to the env's "ep_stats" slot HERE, before an auto-reset wipes the counters;
+        // ftl_episode_metrics() sums the slots.  Rare (one step in a few hundred per env), so one lane's read-modify-write will do.
+        if (E.valid && E.r == 0 && E.done && (!done0 || (C.flags & FTL_STEP_AUTO_RESET))) {
+            double* st = P.ep_stats + (size_t)E.env * FTL_N_METRICS;
+            st[FTL_M_EPISODES] += 1.0; st[FTL_M_RETURN_SUM] += E.overall_reward; st[FTL_M_FRAMES_SUM] += (double)E.step_count;
+            if (i0 == FTL_MISSION_SUCCESS) st[FTL_M_SUCCESS] += 1.0;
+            if (i1 == FTL_AGENT_CRASH) st[FTL_M_CRASH] += 1.0;
+            if (i1 == FTL_AGENT_LOW_REWARD) st[FTL_M_LOW_REWARD] += 1.0;
+            if (i1 == FTL_AGENT_TOO_FAR) st[FTL_M_TOO_FAR] += 1.0;
+            if (i0 == FTL_MISSION_FINISHED_BY_TIME) st[FTL_M_TIMEOUT] += 1.0;
+        }
         bool go = E.valid && E.done && (C.flags & FTL_STEP_AUTO_RESET);
         if (__ballot(go) != 0ull) {
 #ifdef FTL_PROFILE_PATHS
             if (threadIdx.x == 0) s_cyc[12] = 1;
 #endif
-            if (go) E.episodes += 1;
+            if (go) { E.episodes += 1; E.err_acc |= E.error; }
             g_reset<G>(P, E, go ? (E.scen + P.n_envs) % P.scen.n_scenarios : E.scen, go);
             __syncthreads();
         }

@@ -109,7 +109,7 @@ class Game:
             self._vec.load_scenarios(self._generated_pool())
         self._resets_since_seed += 1
         idx = torch.tensor([self._seed % self._vec.pool.n], dtype=torch.int32)
-        self._vec.reset(idx)
+        self._vec.reset(idx, check_errors=True)       # a reference reset() that raises (SEN:893, 288-297) raises here too
         self.simulation_number += 1
         self.done = bool(self._vec.done[0].item())
         return self._obs()
@@ -125,7 +125,7 @@ class Game:
             action = (0.25, float(np.asarray(action).reshape(-1)[-1]))  # command of ENV:910-911 is overwritten by ENV:927
         self._act[0, 0] = float(action[0])
         self._act[0, 1] = float(action[1])
-        self._vec.step(self._act)
+        self._vec.step(self._act, check_errors=True)  # the reference's exceptions instead of silent error bits
         st = self._vec.status[0].cpu().numpy()
         info = {"mission_status": abi.MISSION[st[0]], "agent_status": abi.AGENT[st[1]], "leader_status": abi.LEADER[st[2]]}
         self.done = bool(self._vec.done[0].item())

@@ -2,7 +2,12 @@
 
 Envs are fully independent: rank r of W owns a contiguous block of env indices, there is no exchange inside
 ``step``.  The only collective is an all-reduce of the episode-metrics vector (64 B) every K steps -- RCCL over xGMI
-on GPUs (backend "nccl" is RCCL on ROCm), gloo in the CPU tests."""
+on GPUs (backend "nccl" is RCCL on ROCm), gloo in the CPU tests.
+
+``bench.py`` uses exactly these functions: ``scenario_index`` for the initial scenario of every global env,
+``VecGame.episode_metrics()`` (the vector the frame kernel accumulates on the device, include/ftl.h FTL_M_*) as the
+per-rank vector and ``reduce_metrics`` for the collective.  ``episode_metrics_from_outputs`` is the host-side
+definition of the same vector from step outputs: the tests use it to check the device accumulator."""
 from dataclasses import dataclass
 
 import torch
@@ -37,9 +42,11 @@ def scenario_index(seed, env_lo, n, pool_size):
     return ((e + seed * 1000003) % pool_size).to(torch.int32)
 
 
-def episode_metrics(done, status, reward_sum, frames):
-    """Per-shard metrics vector [episodes, sum return, sum frames, n_success, n_crash, n_low_reward, n_too_far,
-    n_timeout] (f64[8]) from the outputs of one step; status = [n,3] codes of include/ftl.h."""
+def episode_metrics_from_outputs(done, status, reward_sum, frames):
+    """Metrics vector [episodes, sum return, sum frames, n_success, n_crash, n_low_reward, n_too_far, n_timeout] (f64[8])
+    of the episodes that END in one step: ``done`` = the env's episode finished in this step, status = [n,3] codes of
+    include/ftl.h at that step, ``reward_sum`` / ``frames`` = overall_reward and step_count of every env after the step
+    (ENV:941-944)."""
     d = done.bool()
     st = status
     f64 = torch.float64

@@ -84,6 +84,20 @@ class ScenarioPool:
                    z["robot_rect"][:n].astype(np.int32), routes, trajs, device)
 
 
+def error_for_bits(bits, n_envs=1):
+    """Exception object for a set of FTL_ERR_* bits: the type the reference raises where it has one."""
+    where = "%d env(s)" % n_envs
+    if bits & abi.FTL_ERR_TRACKER_SEED:         # SEN:264-297 (the tracker is scanned before every ray sensor, CLS:263-267)
+        return IndexError("pop from an empty deque (tracker seeded with fewer than 2 points or trimmed before the corridor "
+                          "exists, sensors.py:288-297; %s)" % where)
+    if bits & abi.FTL_ERR_EMPTY_CORRIDOR:       # SEN:893/962: `all_obs_arr` is unbound when len(corridor) <= 1
+        return UnboundLocalError("local variable 'all_obs_arr' referenced before assignment (ray sensor scanned with a "
+                                 "corridor of <= 1 points, sensors.py:893-962; %s)" % where)
+    names = [n for b, n in ((abi.FTL_ERR_TRAJ_OVERFLOW, "traj_cap"), (abi.FTL_ERR_CORR_OVERFLOW, "corr_cap")) if bits & b]
+    return _lib.FtlError("capacity overflow of the batched state (%s) in %s: results after the overflow differ from the "
+                         "reference -- raise the capacity in make_config()" % (", ".join(names) or hex(bits), where))
+
+
 class VecGame:
     """N parallel envs on one GPU.
 
@@ -122,14 +136,18 @@ class VecGame:
         o = abi.Outputs()
         o.obs_num, o.lasers, o.target = self.obs_num.data_ptr(), self.lasers.data_ptr(), self.target.data_ptr()
         o.reward, o.done, o.status = self.reward.data_ptr(), self.done.data_ptr(), self.status.data_ptr()
-        # fused ContinuousObserveModifier_sensorPrev output (wrappers.py:169-221): [n, H, sum of row widths], float32
-        hs = {l.history for l in self.cfg.lasers}
+        # fused ContinuousObserveModifier_sensorPrev output (wrappers.py:169-221): [n, H, sum of row widths], float32, over the
+        # sensor classes the wrapper concatenates (LaserSpec.in_policy_obs), in dict order
+        sel = [l for l in self.cfg.lasers if l.in_policy_obs]
+        hs = {l.history for l in sel}
         self.policy_obs = None
-        if policy_obs and self.cfg.lasers:
+        if policy_obs and sel:
             if len(hs) != 1:
-                raise ValueError("policy_obs needs the same max_prev_obs on every ray sensor (wrappers.py:214-215 asserts it)")
-            self.policy_obs = torch.zeros(self.n, hs.pop(), sum(l.width for l in self.cfg.lasers), dtype=torch.float32, **z)
+                raise ValueError("policy_obs needs the same max_prev_obs on every sensor it concatenates (wrappers.py:207, 217 assert it)")
+            self.policy_obs = torch.zeros(self.n, hs.pop(), sum(l.width for l in sel), dtype=torch.float32, **z)
             o.policy_obs = self.policy_obs.data_ptr()
+        self._metrics = torch.zeros(abi.FTL_N_METRICS, dtype=torch.float64, **z)
+        self._errors = torch.zeros(2, dtype=torch.int32, **z)
         self._out = o
         self.pool = None
         self._fields = {}
@@ -153,7 +171,7 @@ class VecGame:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def reset(self, scen_idx=None, mask=None):
+    def reset(self, scen_idx=None, mask=None, check_errors=False):
         if self.pool is None:
             raise _lib.FtlError("load_scenarios() first")
         if scen_idx is None:
@@ -169,16 +187,58 @@ class VecGame:
             mptr = mask.data_ptr()
         self._keep = (scen_idx, mask)
         _lib.check(self.lib.ftl_reset(self.h, scen_idx.data_ptr(), mptr, C.byref(self._out), self._stream()), self.lib)
+        if check_errors:
+            self.raise_on_errors()
         return self.obs_num, self.lasers
 
-    def step(self, action, auto_reset=False):
-        """action: f64[N,2] device tensor = (speed px/frame, signed rotation deg/frame) (ENV:927-933)."""
+    def step(self, action, auto_reset=False, check_errors=False):
+        """action: f64[N,2] device tensor = (speed px/frame, signed rotation deg/frame) (ENV:927-933).
+        ``check_errors=True`` synchronises and raises what the reference would have raised in any env (``raise_on_errors``);
+        the default leaves the per-env sticky error words for ``error_report()`` so that the step stays asynchronous."""
         if action.dtype != torch.float64 or not action.is_contiguous() or action.device != self.device \
                 or tuple(action.shape) != (self.n, 2):
             raise ValueError("action must be a contiguous float64 [n_envs, 2] tensor on %s" % self.device)
         flags = abi.FTL_STEP_AUTO_RESET if auto_reset else 0
         _lib.check(self.lib.ftl_step(self.h, action.data_ptr(), C.byref(self._out), flags, self._stream()), self.lib)
+        if check_errors:
+            self.raise_on_errors()
         return self.obs_num, self.lasers, self.reward, self.done, self.status
+
+    # ------------------------------------------------------------------ episode metrics / error report
+    def episode_metrics(self, clear=False):
+        """f64[8] device tensor ``[episodes, sum return, sum frames, n_success, n_crash, n_low_reward, n_too_far, n_timeout]``
+        over the episodes that ended since the state was created (or since the last ``clear=True`` call): what the
+        reference reports at ``done`` (ENV:941-944), accumulated on the device before auto-reset wipes the counters.
+        This is the vector a multi-GPU job all-reduces (``shard.reduce_metrics``).  Also refreshes ``error_report()``."""
+        flags = abi.FTL_METRICS_CLEAR if clear else 0
+        _lib.check(self.lib.ftl_episode_metrics(self.h, self._metrics.data_ptr(), self._errors.data_ptr(), flags, self._stream()), self.lib)
+        return self._metrics
+
+    def kernel_timing(self, enable=True):
+        """Measurement hook: HIP events around every kernel of the following steps (``kernel_times``)."""
+        _lib.check(self.lib.ftl_kernel_timing(self.h, 1 if enable else 0), self.lib)
+
+    def kernel_times(self):
+        """Average per-kernel duration in microseconds over the steps timed since the last call:
+        ``dict(frames_us, rays_us, regroup_us, steps)`` (regroup = both regroup kernels, averaged over ALL steps)."""
+        ms, n = (C.c_double * 3)(), C.c_int32()
+        _lib.check(self.lib.ftl_kernel_times(self.h, C.byref(ms), C.byref(n)), self.lib)
+        k = max(n.value, 1)
+        return dict(frames_us=ms[0] / k * 1e3, rays_us=ms[1] / k * 1e3, regroup_us=ms[2] / k * 1e3, steps=n.value)
+
+    def error_report(self):
+        """(number of envs whose sticky error word is set, OR of the FTL_ERR_* bits) -- the conditions under which a
+        reference run would have raised (or a capacity of the batched state overflowed).  The words survive reset and
+        auto-reset; ``episode_metrics(clear=True)`` clears them together with the metrics records."""
+        self.episode_metrics()
+        n, bits = self._errors.tolist()
+        return int(n), int(bits)
+
+    def raise_on_errors(self):
+        """The exception the reference would have raised (or FtlError for a capacity overflow) if any env reported one."""
+        n, bits = self.error_report()
+        if bits:
+            raise error_for_bits(bits, n)
 
     # ------------------------------------------------------------------ views
     def laser_view(self, name):

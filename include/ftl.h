@@ -76,7 +76,8 @@ typedef struct ftl_laser_cfg {
     int32_t pad_sectors;      /* SEN:932-953: rows are [front|right|behind|left], 4*count wide, zeros outside a ray's sector */
     int32_t lenient;          /* 1: LeaderCorridor_lasers_v2 (SEN:736-807) -- one row of the current edges, and a corridor of <= 1 points
                                  reads laser_length on every ray instead of raising (no FTL_ERR_EMPTY_CORRIDOR) */
-    int32_t _pad;
+    int32_t in_policy_obs;    /* 1: the sensor is one of the classes ContinuousObserveModifier_sensorPrev concatenates
+                                 (LeaderCorridor_Prev_lasers_v2/_v3 and LeaderCorridor_lasers_compas, utils/wrappers.py:204, 214) */
     double length;            /* laser_length, px */
     double angle_offset;      /* first_laser_angle_offset, deg */
     int32_t explicit_angles;  /* 1: LeaderCorridor_lasers (SEN:571-702) -- ray i points at direction + ray_angles[i] instead of a full circle */
@@ -215,8 +216,8 @@ typedef struct ftl_outputs {
     uint8_t* done;       /* [n] */
     uint8_t* status;     /* [n][3]             mission / agent / leader status codes */
     float*   policy_obs; /* optional (may be NULL): [n][H][sum_k width_k] = ContinuousObserveModifier_sensorPrev.observation
-                            (utils/wrappers.py:200-221): per sensor clip(x / laser_length, 0, 1), concatenated along axis 1;
-                            requires every ray sensor to have the same history H */
+                            (utils/wrappers.py:200-221): per sensor with in_policy_obs set clip(x / laser_length, 0, 1),
+                            concatenated along axis 1; those sensors must share one history H (wrappers.py:183-188) */
 } ftl_outputs;
 
 typedef struct ftl_handle ftl_handle;
@@ -234,7 +235,10 @@ int32_t ftl_lasers_len(const ftl_handle* h);
 /* copy of the frozen config (out_offset of every laser filled in) */
 int ftl_get_config(const ftl_handle* h, ftl_config* out);
 
-/* Per-env mutable state lives in ONE caller-owned device buffer (a torch uint8 tensor). */
+/* Per-env mutable state lives in ONE caller-owned device buffer (a torch uint8 tensor).  A fresh buffer MUST be
+ * zero-initialised: the reset path relies on zeroed FTL_EI_FPS / FTL_EI_RESETS / FTL_EI_ACC_CONSUMED / FTL_EI_EPISODES /
+ * FTL_EI_ERROR_STICKY words and on a zeroed "ep_stats" field (they survive reset() like the attributes of the reference's
+ * Game object that reset() does not touch).  A buffer that already holds the state of an earlier run may be bound again. */
 size_t ftl_state_bytes(const ftl_handle* h);
 int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes);
 
@@ -252,6 +256,33 @@ int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const
 
 /* step(action) (ENV:908-945) for all envs: action[n][2] = (speed px/frame, signed rotation deg/frame) as f64. */
 int ftl_step(ftl_handle* h, const double* action, const ftl_outputs* out, uint32_t flags, void* stream);
+
+/* ---- episode metrics + error report (ENV:941-944 reports overall_reward / step_count at done) --------
+ * Every env slot accumulates, at the step in which an episode ends (done set by this step; under FTL_STEP_AUTO_RESET
+ * before the slot is re-initialised), the vector below in its "ep_stats" state field (f64[FTL_N_METRICS] per env).
+ * ftl_episode_metrics sums those records over the envs of the handle in a fixed order (bit-reproducible) into
+ * dev_metrics[FTL_N_METRICS] (DEVICE pointer) -- the 64-byte vector a multi-GPU job all-reduces -- and reports the
+ * sticky error words: dev_errors[0] = number of envs whose FTL_EI_ERROR_STICKY is non-zero, dev_errors[1] = OR of them
+ * (DEVICE pointer, may be NULL).  FTL_METRICS_CLEAR zeroes the per-env records and sticky words afterwards. */
+#define FTL_N_METRICS 8
+enum { FTL_M_EPISODES = 0,   /* finished episodes */
+       FTL_M_RETURN_SUM,     /* sum of overall_reward at done (ENV:943) */
+       FTL_M_FRAMES_SUM,     /* sum of step_count at done, in frames (ENV:944) */
+       FTL_M_SUCCESS,        /* mission_status == success at done */
+       FTL_M_CRASH,          /* agent_status == crash */
+       FTL_M_LOW_REWARD,     /* agent_status == low_reward */
+       FTL_M_TOO_FAR,        /* agent_status == too_far_from_leader */
+       FTL_M_TIMEOUT };      /* mission_status == finished_by_time */
+#define FTL_METRICS_CLEAR 1u
+int ftl_episode_metrics(ftl_handle* h, double* dev_metrics, int32_t* dev_errors, uint32_t flags, void* stream);
+
+/* ---- measurement hook (bench.py): per-kernel durations from HIP events on the launch stream ------------------------------
+ * While enabled every ftl_step records events around its launches (frame kernel, ray kernel, the two regroup kernels);
+ * ftl_kernel_times synchronises and returns the SUM of the durations in milliseconds since the last call as
+ * ms[3] = {frames, rays, regroup} and the number of steps they cover.  At most 512 steps are held; not available in the
+ * two-stream mode (returns FTL_E_UNSUPPORTED).  Off by default: the events cost a few microseconds per step. */
+int ftl_kernel_timing(ftl_handle* h, int32_t enable);
+int ftl_kernel_times(ftl_handle* h, double* ms, int32_t* n_steps);
 
 const char* ftl_last_error(void);
 
@@ -274,6 +305,8 @@ enum {
     FTL_EI_HINT_X, FTL_EI_HINT_Y, FTL_EI_CLR_GREEN, FTL_EI_CLR_ALL,
     FTL_EI_FPS,        /* frames of the NEXT step of this env under random_frames_per_step (drawn at the end of a step, ENV:939-940;
                           kept across resets like the reference's attribute; 0 = not drawn yet) */
+    FTL_EI_ERROR_STICKY, /* OR of every FTL_ERR_* bit this env slot ever raised: survives reset / auto-reset (FTL_EI_ERROR is per
+                          episode); cleared by ftl_episode_metrics(FTL_METRICS_CLEAR) */
     FTL_EI_COUNT
 };
 /* indices into the "env_dbl" state field; bear waypoints follow at FTL_ED_BEAR_POINTS + 2*b */

@@ -135,6 +135,16 @@ CONFIGS = {
                                    "back_lasers_count": 2, "laser_length": 90})])), post=None),
     # three bears (odd index -> _move_bear_v4), sensors of B
     "B3": dict(kwargs=dict(bear_number=3, follower_sensors=SENSORS_B), post=None),
+    # config M ("mixed"): a Prev_lasers_v2 sensor next to a LeaderCorridor_lasers_v2 one and FollowerInfo, every entry with a
+    # "sensor_class" key so that ContinuousObserveModifier_sensorPrev constructs on it -- the wrapper must pick the Prev sensor
+    # only (wrappers.py:204, 214)
+    "M": dict(kwargs=dict(bear_number=1, follower_sensors=OrderedDict([
+        ("LeaderPositionsTracker_v2", dict(SENSORS_B["LeaderPositionsTracker_v2"])),
+        ("lasers_now", {"sensor_class": "LeaderCorridor_lasers_v2", "react_to_obstacles": True, "react_to_green_zone": True,
+                        "react_to_safe_corridor": True, "lasers_count": 24, "laser_length": 130}),
+        ("LeaderCorridor_lasers_all", dict(SENSORS_B["LeaderCorridor_lasers_all"])),
+        ("FollowerInfo", {"sensor_class": "FollowerInfo"}),
+        ("LeaderCorridor_lasers_obstacles", dict(SENSORS_B["LeaderCorridor_lasers_obstacles"], pad_sectors=True))])), post=None),
 }
 
 
@@ -313,10 +323,28 @@ def random_action(g, rng):
     return (float(v), w)
 
 
+def sensor_prev_wrapper(g):
+    """The reference's own ContinuousObserveModifier_sensorPrev (utils/wrappers.py:169-221) around the Game, or None when its
+    constructor cannot run on this sensor dict (it indexes sensor_config["sensor_class"] / ["pad_sectors"] unconditionally)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import continuous_grid_arctic.utils.wrappers as WRP
+    hs = {v.get("max_prev_obs") for v in g.follower_sensors.values()
+          if v.get("sensor_class") in ("LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_Prev_lasers_v3", "LeaderCorridor_lasers_compas")}
+    if len(hs) != 1:
+        return None
+    try:
+        return WRP.ContinuousObserveModifier_sensorPrev(g, max_prev_obs=hs.pop())
+    except KeyError:
+        return None
+
+
 def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_done=3):
     r = Runner(config_name)
     obs0 = r.reset(seed)
     g = r.game
+    wrap = sensor_prev_wrapper(g)
     laser_names = [k for k, v in g.follower_sensors.items()
                    if v.get("sensor_class", k) in ("LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2", "LeaderCorridor_lasers")]
     scen = scenario_of(g)
@@ -325,6 +353,8 @@ def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_do
         out["reset:" + k] = v
     for k, v in debug_record(g).items():
         out["reset_dbg:" + k] = v
+    if wrap is not None:      # observation() is a pure function of the obs dict (+ the sensors' laser_length)
+        out["reset:wrap_sensorPrev"] = np.asarray(wrap.observation(obs0)).copy()
     rng = np.random.default_rng(1000 + seed)
     acts, rews, dones, infos = [], [], [], []
     obs_rows = {}
@@ -348,6 +378,8 @@ def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_do
         infos.append([MISSION[info["mission_status"]], AGENT[info["agent_status"]], LEADER[info["leader_status"]]])
         for k, v in obs_record(g, obs, laser_names).items():
             obs_rows.setdefault(k, []).append(v)
+        if wrap is not None:
+            obs_rows.setdefault("wrap_sensorPrev", []).append(np.asarray(wrap.observation(obs)).copy())
         if t % debug_every == 0:
             for k, v in debug_record(g).items():
                 dbg_rows.setdefault(k, []).append(v)
@@ -395,6 +427,8 @@ EPISODES = [
     ("Bes_s6_chase", "B_es", 6, "chase_noisy", 200),
     ("B3_s8_chase", "B3", 8, "chase", 250),
     ("D_s2_chase", "D", 2, "chase", 60),
+    ("D_s7_random", "D", 7, "random", 60),
+    ("M_s3_chase", "M", 3, "chase", 100),
     ("Bshort_s4_chase", "B_short", 4, "chase", 60),
     ("Bshort_s9_random", "B_short", 9, "random", 60),
     ("Bnobear_s1_chase", "B_nobear", 1, "chase", 520),

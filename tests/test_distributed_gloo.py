@@ -1,7 +1,8 @@
 """The N>1 path on CPU: two gloo ranks shard a batch of envs (contiguous ranges, scenario index by GLOBAL env id, no
 data-path exchange), step their shards with the CPU oracle standing in for the device kernels, and all-reduce the
-episode-metrics vector -- the result must equal the single-process run.  This is the exact host logic bench.py uses
-with RCCL on GPUs (shard.py)."""
+episode-metrics vector -- the result must equal the single-process run.  bench.py uses the same shard.scenario_index /
+shard.reduce_metrics with RCCL on GPUs; its per-rank vector comes from the device accumulator (VecGame.episode_metrics),
+which tests/test_gpu_metrics.py checks against shard.episode_metrics_from_outputs -- the definition used here."""
 import json
 import os
 import socket
@@ -38,10 +39,11 @@ def _run_shard(lo, hi):
             e = lo + k                                   # actions keyed by the GLOBAL env id
             rng = np.random.default_rng(1000 * t + e)
             _, r, d, s = o.step((rng.uniform(0.1, 0.25), rng.normal(0, 0.1)))
-            ret[k] += r; frames[k] += 10
+            dbg = o.debug()
+            ret[k] = dbg["acc"][1]; frames[k] = dbg["counters"][0]       # overall_reward, step_count (ENV:941-944)
             done[k] = d and not finished[k]; st[k] = s
             finished[k] |= d
-        total += shard.episode_metrics(torch.from_numpy(done), torch.from_numpy(st), torch.from_numpy(ret), torch.from_numpy(frames))
+        total += shard.episode_metrics_from_outputs(torch.from_numpy(done), torch.from_numpy(st), torch.from_numpy(ret), torch.from_numpy(frames))
     return total
 
 

@@ -221,16 +221,12 @@ def test_full_size_properties_65536_envs():
     big.close(); small.close()
 
 
-def sensor_prev_observation(obs_by_name, lasers):
-    """numpy restatement of ContinuousObserveModifier_sensorPrev.observation (reference utils/wrappers.py:200-221):
-    per ray sensor np.clip(x / laser_length, 0, 1), concatenated along axis 1."""
-    feats = [np.clip(obs_by_name[l.name] / l.length, 0, 1) for l in lasers]
-    return np.concatenate(feats, axis=1)
-
-
-@pytest.mark.parametrize("name", ["B_s1_chase", "Bpad_s4_chase"])
+@pytest.mark.parametrize("name", ["B_s1_chase", "Bpad_s4_chase", "F_s7_chase", "M_s3_chase"])
 def test_fused_sensor_prev_wrapper_output(name):
-    """Row f1 of the scope table: the policy input tensor written by the ray kernel's epilogue."""
+    """Row f1 of the scope table: the policy input tensor written by the ray kernel's epilogue, against the output of the
+    reference's OWN ContinuousObserveModifier_sensorPrev.observation (utils/wrappers.py:200-221) recorded by make_golden.py
+    (`wrap_sensorPrev`).  Config M mixes a LeaderCorridor_lasers_v2 sensor in: the wrapper -- and policy_obs -- take the
+    Prev_lasers_v2 sensors only (wrappers.py:204, 214); F registers ten snapshots and the tracker last."""
     from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
     z, meta = load_episode(name)
     cfg = config_for(meta, scen_route_len=len(z["scen:route"]))
@@ -239,13 +235,16 @@ def test_fused_sensor_prev_wrapper_output(name):
     env.load_scenarios(ScenarioPool(cfg, s["static_rects"][None], s["robot_pos"][None], s["robot_dir"][None], s["robot_rect"][None],
                                     [s["route"]], [s["init_traj"]], "cuda:0"))
     env.reset(torch.zeros(2, dtype=torch.int32))
-    H = cfg.lasers[0].history
-    assert tuple(env.policy_obs.shape) == (2, H, sum(l.width for l in cfg.lasers)) and env.policy_obs.dtype == torch.float32
+    sel = [l for l in cfg.lasers if l.in_policy_obs]
+    assert len(sel) < len(cfg.lasers) or not name.startswith("M_")
+    assert tuple(env.policy_obs.shape) == (2,) + z["reset:wrap_sensorPrev"].shape and env.policy_obs.dtype == torch.float32
+    assert np.abs(env.policy_obs[0].cpu().numpy() - z["reset:wrap_sensorPrev"]).max() <= 1e-5
+    envs = [0] if cfg.c.rand_fps_hi > 0 else [0, 1]       # per-env counter streams: only env 0 replays a random-frame episode
     for t in range(min(60, len(z["actions"]))):
         env.step(torch.tensor(np.tile(z["actions"][t], (2, 1)), dtype=torch.float64, device="cuda:0"))
-        ref = sensor_prev_observation({l.name: z["obs:laser:" + l.name][t] for l in cfg.lasers}, cfg.lasers)
+        ref = z["obs:wrap_sensorPrev"][t]
         got = env.policy_obs.cpu().numpy()
         assert got.min() >= 0.0 and got.max() <= 1.0
-        for e in range(2):
+        for e in envs:
             assert np.abs(got[e] - ref).max() <= 1e-5, (name, t, np.abs(got[e] - ref).max())
     env.close()
