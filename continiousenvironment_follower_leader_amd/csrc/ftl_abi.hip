@@ -284,7 +284,8 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         const int count = my_groups * epw0;              // slots of this launch (the tail of the last group may be idle)
         const bool reg = h->P.cfg.n_speed_regime >= 0 || h->P.cfg.n_acc_regime >= 0 || h->P.cfg.rand_fps_hi > 0;
         const int epw = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
-        const size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
+        size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
+        if (const char* pad = getenv("FTL_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);      // diagnostic: lower the occupancy without touching the code
         const dim3 grid((count + epw - 1) / epw), block(FTL_WAVE);
         if (tev) (void)hipEventRecord(tev[0], s);
         if (h->P.R <= 4) {

@@ -25,6 +25,33 @@ template <int G, int K> __device__ __forceinline__ float gb_f(float v) { return 
 template <int G, int K> __device__ __forceinline__ double gb_d(double v) {
     return __hiloint2double(gb_i<G, K>(__double2hiint(v)), gb_i<G, K>(__double2loint(v)));
 }
+// value of lane (r ^ off) of this lane's group.  Offsets 1 and 2 never leave a quad: one DPP move (quad_perm) instead of a
+// ds_bpermute round trip through the LDS unit -- this kernel is bound by dependent-instruction latency.
+__device__ __forceinline__ int gx_i(int v, int off, int G) {
+    if (off == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);      // quad_perm:[1,0,3,2]
+    if (off == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);      // quad_perm:[2,3,0,1]
+    return __shfl_xor(v, off, G);
+}
+__device__ __forceinline__ float gx_f(float v, int off, int G) { return __int_as_float(gx_i(__float_as_int(v), off, G)); }
+__device__ __forceinline__ double gx_d(double v, int off, int G) { return __hiloint2double(gx_i(__double2hiint(v), off, G), gx_i(__double2loint(v), off, G)); }
+__device__ __forceinline__ float gx(float v, int off, int G) { return gx_f(v, off, G); }
+__device__ __forceinline__ int gx(int v, int off, int G) { return gx_i(v, off, G); }
+__device__ __forceinline__ double gx(double v, int off, int G) { return gx_d(v, off, G); }
+// value of lane (r - off) of the group (whatever for r < off), off = 1 or 2
+template <int G> __device__ __forceinline__ double g_up_d(double v, int off) {
+    if constexpr (G == 4) {
+        const int hi = __double2hiint(v), lo = __double2loint(v);
+        if (off == 1) return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x90, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x90, 0xf, 0xf, false));   // quad_perm:[0,0,1,2]
+        return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x44, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x44, 0xf, 0xf, false));                  // quad_perm:[0,1,0,1]
+    } else return __shfl_up(v, off, G);
+}
+// value of lane k (group-uniform, run-time) of the group
+template <int G> __device__ __forceinline__ float g_pick_f(float v, int k) {
+    if constexpr (G == 4) {
+        const float a = gb_f<4, 0>(v), b = gb_f<4, 1>(v), c2 = gb_f<4, 2>(v), d = gb_f<4, 3>(v);
+        return k == 0 ? a : k == 1 ? b : k == 2 ? c2 : d;
+    } else return __shfl(v, k, G);
+}
 template <int G> __device__ __forceinline__ bool group_any(bool p) {
     unsigned long long m = __ballot(p);
     return ((m >> (threadIdx.x & ~(G - 1))) & ((1ull << G) - 1ull)) != 0ull;
@@ -33,22 +60,22 @@ template <int G> __device__ __forceinline__ double group_excl_scan(double v, int
     double incl = v;
 #pragma unroll
     for (int off = 1; off < G; off <<= 1) {
-        double o = __shfl_up(incl, off, G);
+        double o = g_up_d<G>(incl, off);
         if (r >= off) incl += o;
     }
-    total = __shfl(incl, G - 1, G);
+    total = gb_d<G, G - 1>(incl);
     return incl - v;
 }
 template <int G> __device__ __forceinline__ int group_sum(int v) {
 #pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, G);
+    for (int off = G / 2; off >= 1; off >>= 1) v += gx(v, off, G);
     return v;
 }
 template <int G> __device__ __forceinline__ void group_argmin(float& v, int& idx) {     // first-index ties (np.argmin)
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) {
-        float ov = __shfl_xor(v, off, G);
-        int oi = __shfl_xor(idx, off, G);
+        float ov = gx(v, off, G);
+        int oi = gx(idx, off, G);
         bool take = (ov < v) || (ov == v && oi < idx);
         if (take) { v = ov; idx = oi; }
     }
@@ -313,7 +340,7 @@ __device__ __forceinline__ int g_green_walk(const FtlDevParams& P, const GCtx& E
     }
     Gc = group_sum<G>(Gc);
 #pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, off, G));
+    for (int off = G / 2; off >= 1; off >>= 1) wmax = fmax(wmax, gx(wmax, off, G));
     tiny = group_any<G>(small) || maxd > 500.0;
     if (tiny && group_any<G>(near)) {
         Gc = g_green_seq(tr, n, maxd);
@@ -369,7 +396,7 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
         if (!(bd2 <= bound)) skipmin = fminf(skipmin, bd2);   // per lane; combined over the group at the end
         while (m) {                                           // group-uniform: every lane of the group sees the same mask
             int k = __ffs(m) - 1; m &= m - 1;
-            float kd2 = __shfl(bd2, k, G);
+            float kd2 = g_pick_f<G>(bd2, k);
             if (!(kd2 <= bound)) { skipmin = fminf(skipmin, kd2); continue; }   // the bound may have tightened since the mask was formed
             int s0 = (b0 + k) * FTL_TRAJ_BLOCK;
             int i0 = max(s0, lo), i1 = min(s0 + FTL_TRAJ_BLOCK, hi);
@@ -383,18 +410,18 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
             }
             float gbest = best;                               // tighten the bound with what the group has seen so far
 #pragma unroll
-            for (int off = G / 2; off >= 1; off >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, off, G));
+            for (int off = G / 2; off >= 1; off >>= 1) gbest = fminf(gbest, gx(gbest, off, G));
             bound = fminf(bound, gbest);
         }
     }
     // combine the lanes: smallest d2, then earliest in the reference's enumeration order
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) {
-        float ov = __shfl_xor(best, off, G); int ok = __shfl_xor(key, off, G); int oi = __shfl_xor(bi, off, G);
-        float ox = __shfl_xor(bp.x, off, G), oy = __shfl_xor(bp.y, off, G);
+        float ov = gx(best, off, G); int ok = gx(key, off, G); int oi = gx(bi, off, G);
+        float ox = gx(bp.x, off, G), oy = gx(bp.y, off, G);
         bool take = (ov < best) || (ov == best && ok < key);
         if (take) { best = ov; key = ok; bi = oi; bp.x = ox; bp.y = oy; }
-        skipmin = fminf(skipmin, __shfl_xor(skipmin, off, G));
+        skipmin = fminf(skipmin, gx(skipmin, off, G));
     }
 }
 
@@ -645,21 +672,21 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             }
 #pragma unroll
             for (int off = G / 2; off >= 1; off >>= 1) {
-                float ov = __shfl_xor(wbest, off, G); int oi = __shfl_xor(widx, off, G);
-                float ox = __shfl_xor(wp.x, off, G), oy = __shfl_xor(wp.y, off, G);
+                float ov = gx(wbest, off, G); int oi = gx(widx, off, G);
+                float ox = gx(wp.x, off, G), oy = gx(wp.y, off, G);
                 bool take = (ov < wbest) || (ov == wbest && oi < widx);
                 if (take) { wbest = ov; widx = oi; wp.x = ox; wp.y = oy; }
             }
 #pragma unroll
             for (int off = G / 2; off >= 1; off >>= 1) {
-                float ov = __shfl_xor(gbest, off, G); int oi = __shfl_xor(gidx, off, G);
-                float ox = __shfl_xor(gp.x, off, G), oy = __shfl_xor(gp.y, off, G);
+                float ov = gx(gbest, off, G); int oi = gx(gidx, off, G);
+                float ox = gx(gp.x, off, G), oy = gx(gp.y, off, G);
                 bool take = (ov < gbest) || (ov == gbest && oi != 0x7fffffff && (gidx == 0x7fffffff || oi > gidx));
                 if (take) { gbest = ov; gidx = oi; gp.x = ox; gp.y = oy; }
             }
 #pragma unroll
             for (int off = G / 2; off >= 1; off >>= 1) {
-                int oi = __shfl_xor(aidx, off, G); float ox = __shfl_xor(ap.x, off, G), oy = __shfl_xor(ap.y, off, G);
+                int oi = gx(aidx, off, G); float ox = gx(ap.x, off, G), oy = gx(ap.y, off, G);
                 if (oi > aidx) { aidx = oi; ap.x = ox; ap.y = oy; }
             }
         }
@@ -784,9 +811,9 @@ __device__ __forceinline__ T g_pw128(const FtlDevParams& P, int env, int r, int 
     }
     T res = acc[0];
     if constexpr (APL == 2) res = acc[0] + acc[1];                               // r_{2k} + r_{2k+1}
-    else res = res + __shfl_xor(res, 1, G);
-    res = res + __shfl_xor(res, APL == 2 ? 1 : 2, G);                             // (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)
-    res = res + __shfl_xor(res, APL == 2 ? 2 : 4, G);
+    else res = res + gx(res, 1, G);
+    res = res + gx(res, APL == 2 ? 1 : 2, G);                             // (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)
+    res = res + gx(res, APL == 2 ? 2 : 4, G);
     for (; i < n; i++) res += (T)g_hist_dist(P, env, first + i, f64);
     return res;
 }
