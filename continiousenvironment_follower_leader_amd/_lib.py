@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libftl_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", "ftl_abi.hip"), os.path.join(_PKG, "csrc", "ftl_device.hpp"),
-           os.path.join(_PKG, "csrc", "ftl_frames_group.hpp"), os.path.join(_PKG, "csrc", "ftl_scenario.cpp"),
+           os.path.join(_PKG, "csrc", "ftl_frames_group.hpp"), os.path.join(_PKG, "csrc", "ftl_aux.hpp"), os.path.join(_PKG, "csrc", "ftl_scenario.cpp"),
            os.path.join(_ROOT, "include", "ftl.h")]
 # translation units: the device code + C-ABI, and the host-only scenario generator (reset-time, no GPU code)
 UNITS = [os.path.join(_PKG, "csrc", "ftl_abi.hip"), os.path.join(_PKG, "csrc", "ftl_scenario.cpp")]

@@ -4,9 +4,11 @@ Field order and types must match the header exactly; ``tests/test_abi.py`` check
 against ``ftl_sizeof_*`` exported by the library."""
 import ctypes as C
 
-FTL_ABI_VERSION = 1
+FTL_ABI_VERSION = 2
 FTL_MAX_BEARS = 4
 FTL_MAX_LASERS = 4
+FTL_MAX_AUX = 8
+AUX_LIDAR, AUX_TRACK_VECTOR, AUX_TRACK_RADAR = 1, 2, 3
 FTL_MAX_REGIME = 16
 FTL_OBS_NUM = 10
 
@@ -17,7 +19,7 @@ MISSION = ("in_progress", "fail", "success", "finished_by_time")          # ENV:
 AGENT = ("moving", "crash", "low_reward", "too_far_from_leader", "finished")
 LEADER = ("moving", "crash", "finished")
 
-FTL_ERR_TRAJ_OVERFLOW, FTL_ERR_CORR_OVERFLOW, FTL_ERR_EMPTY_CORRIDOR, FTL_ERR_TRACKER_SEED = 1, 2, 4, 8
+FTL_ERR_TRAJ_OVERFLOW, FTL_ERR_CORR_OVERFLOW, FTL_ERR_EMPTY_CORRIDOR, FTL_ERR_TRACKER_SEED, FTL_ERR_HIST1_OVERFLOW = 1, 2, 4, 8, 16
 FTL_STEP_AUTO_RESET = 1
 FTL_N_METRICS = 8
 FTL_METRICS_CLEAR = 1
@@ -28,7 +30,7 @@ FTL_METRICS_CLEAR = 1
  EI_STEP_COUNT, EI_FINISH_TIMER, EI_TRAJ_LEN, EI_TRK_COUNTER, EI_CORR_LO, EI_CORR_HI, EI_SEED_END,
  EI_SNAP_COUNT, EI_DYN_INDEX0, EI_DYN_INDEX1, EI_DYN_INDEX2, EI_DYN_INDEX3, EI_ERROR, EI_EPISODES,
  EI_GREEN_COUNT, EI_GREEN_LEN, EI_SCAN_OK, EI_SNAP_HEAD, EI_HINT, EI_GREEN_TINY, EI_RESETS, EI_ACC_CONSUMED,
- EI_HINT_X, EI_HINT_Y, EI_CLR_GREEN, EI_CLR_ALL, EI_FPS, EI_ERROR_STICKY, EI_COUNT) = range(37)
+ EI_HINT_X, EI_HINT_Y, EI_CLR_GREEN, EI_CLR_ALL, EI_FPS, EI_HW0_LO, EI_HW0_HI, EI_HIST1_LEN, EI_ERROR_STICKY, EI_COUNT) = range(40)
 ED_ACC_PENALTY, ED_OVERALL_REWARD, ED_SPARE0, ED_SPARE1, ED_BEAR_POINTS = range(5)
 ED_GREEN_W = ED_BEAR_POINTS + 2 * FTL_MAX_BEARS
 ED_CUR_MULT, ED_CUR_ACC, ED_CUM_SPEED = ED_GREEN_W + 1, ED_GREEN_W + 2, ED_GREEN_W + 3
@@ -54,7 +56,15 @@ class LaserCfg(C.Structure):
                 ("react_obstacles", C.c_int32), ("history", C.c_int32), ("after_tracker", C.c_int32),
                 ("out_offset", C.c_int32), ("pad_sectors", C.c_int32), ("lenient", C.c_int32), ("in_policy_obs", C.c_int32),
                 ("length", C.c_double), ("angle_offset", C.c_double),
-                ("explicit_angles", C.c_int32), ("_pad2", C.c_int32), ("ray_angles", C.c_double * 8)]
+                ("explicit_angles", C.c_int32), ("compas", C.c_int32), ("ray_angles", C.c_double * 8)]
+
+
+class AuxCfg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("after_tracker", C.c_int32), ("out_offset", C.c_int32), ("out_len", C.c_int32),
+                ("n_angles", C.c_int32), ("points_number", C.c_int32), ("return_all_points", C.c_int32),
+                ("return_only_distances", C.c_int32), ("range_px", C.c_double), ("in_range_px", C.c_double),
+                ("angle_step", C.c_double), ("border_angle", C.c_int32), ("seq_len", C.c_int32),
+                ("detectable", C.c_int32), ("radar_sectors", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -66,7 +76,7 @@ class Config(C.Structure):
                 ("has_max_distance_coef", C.c_int32), ("has_tracker", C.c_int32),
                 ("tracker_saving_period", C.c_int32), ("tracker_start_behind", C.c_int32),
                 ("n_lasers", C.c_int32), ("traj_cap", C.c_int32), ("corr_cap", C.c_int32),
-                ("route_cap", C.c_int32), ("init_traj_cap", C.c_int32), ("_pad0", C.c_int32 * 2),
+                ("route_cap", C.c_int32), ("init_traj_cap", C.c_int32), ("hist1_cap", C.c_int32), ("trk1_eat_close_points", C.c_int32),
                 ("low_reward", C.c_double), ("max_distance_coef", C.c_double),
                 ("min_distance", C.c_double), ("max_distance", C.c_double), ("max_dev", C.c_double),
                 ("leader_pos_epsilon", C.c_double), ("corridor_length", C.c_double),
@@ -81,7 +91,8 @@ class Config(C.Structure):
                 ("acc_key", C.c_int32 * FTL_MAX_REGIME), ("env_id_base", C.c_int32),
                 ("rand_fps_lo", C.c_int32), ("rand_fps_hi", C.c_int32), ("_pad1", C.c_int32),
                 ("speed_lo", C.c_double * FTL_MAX_REGIME), ("speed_hi", C.c_double * FTL_MAX_REGIME),
-                ("acc_val", C.c_double * FTL_MAX_REGIME), ("rng_seed", C.c_uint64)]
+                ("acc_val", C.c_double * FTL_MAX_REGIME), ("rng_seed", C.c_uint64),
+                ("trk1_eat_radius", C.c_double), ("n_aux", C.c_int32), ("_pad2", C.c_int32), ("aux", AuxCfg * FTL_MAX_AUX)]
 
 
 _M64 = (1 << 64) - 1

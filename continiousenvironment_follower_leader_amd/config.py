@@ -16,7 +16,9 @@ REWARD_DEFAULTS = dict(reward_in_box=1.0, reward_on_track=0.1, reward_in_dev=0.5
                        leader_stop_penalty=-1.0)
 
 # SENSOR_CLASSNAME_TO_CLASS (utils/sensors.py:1291-1307): the classes on the accelerated path.
-SUPPORTED_SENSOR_CLASSES = ("LeaderPositionsTracker_v2", "LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2", "LeaderCorridor_lasers", "FollowerInfo")
+SUPPORTED_SENSOR_CLASSES = ("LeaderPositionsTracker_v2", "LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2", "LeaderCorridor_lasers", "FollowerInfo",
+                            "LeaderCorridor_lasers_compas", "LaserSensor", "LeaderPositionsTracker", "LeaderTrackDetector_vector",
+                            "LeaderTrackDetector_radar")
 # classes whose constructor (or scan) raises in the reference itself: exception type and message mirrored (SEN:493-495, 810-864, 993)
 DEPRECATED_SENSOR_CLASSES = {
     "GreenBoxBorderSensor": (ValueError, "To use it, you need to uncomment the call self._get_green_zone_border_points(). Commented out because it slows down the simulation"),
@@ -50,10 +52,31 @@ class LaserSpec:
     lenient: bool = False       # LeaderCorridor_lasers_v2: flat [count] observation, no error on a short corridor
     ray_angles: tuple = None    # LeaderCorridor_lasers: explicit ray directions relative to the heading, deg
     in_policy_obs: bool = False  # one of the classes ContinuousObserveModifier_sensorPrev concatenates (wrappers.py:204, 214)
+    compas: bool = False        # LeaderCorridor_lasers_compas: rows of 5*count (no wall | front | back | left | right), SEN:1138-1288
 
     @property
-    def width(self):            # row width of the sensor's output block (SEN:932-958)
+    def width(self):            # row width of the sensor's output block (SEN:932-958, 1226)
+        if self.compas:
+            return 5 * self.count
         return 4 * self.count if self.pad_sectors else self.count
+
+
+@dataclass
+class AuxSpec:
+    """LaserSensor / LeaderTrackDetector_vector / LeaderTrackDetector_radar: a float32 block after the ray sensors' blocks."""
+    name: str
+    kind: int
+    shape: tuple                # shape of the observation the reference returns
+    after_tracker: bool
+    out_offset: int = 0
+    params: dict = field(default_factory=dict)
+
+    @property
+    def out_len(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
 
 
 @dataclass
@@ -65,6 +88,7 @@ class GameConfig:
     tracker_name: str = None
     sensor_order: list = field(default_factory=list)
     follower_info: list = field(default_factory=list)       # (name, speed_direction_param) of FollowerInfo sensors
+    aux: list = field(default_factory=list)                 # AuxSpec of lidar / leader-track detectors, dict order
     discrete_action_space: bool = False
     constant_follower_speed: bool = False
     discrete_rotation_speed_to_value: dict = None
@@ -78,7 +102,7 @@ class GameConfig:
 
     @property
     def lasers_len(self):
-        return sum(l.history * l.width for l in self.lasers)
+        return sum(l.history * l.width for l in self.lasers) + sum(a.out_len for a in self.aux)
 
 
 def _react_code(v):
@@ -221,8 +245,9 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
          to_px(0.005), to_px(bear_size[1]), to_px(bear_size[0]))      # ENV:706-711
 
     # ---- sensors (CLS:239-253 registry protocol, dict order matters: CLS:269-286) ------------------
-    lasers, tracker_name, order, follower_info = [], None, [], []
+    lasers, tracker_name, order, follower_info, aux = [], None, [], [], []
     seen_tracker = False
+    trk1_generate_corridor = True
     for name, spec in follower_sensors.items():
         spec = dict(spec)
         cls = spec.pop("sensor_class", None)
@@ -252,13 +277,63 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
                 pass
             if not spec.get("generate_corridor", True):
                 raise NotImplementedError("generate_corridor=False leaves `leader_corridor` unbound for the ray sensors")
-            c.has_tracker = 1
+            if c.has_tracker:
+                raise NotImplementedError("one tracker per follower (with both registered the v2 history silently replaces the v1 one, CLS:257-267)")
+            c.has_tracker = 2
             c.tracker_saving_period = int(spec.get("saving_period", 5))
             c.tracker_start_behind = int(bool(spec.get("start_corridor_behind_follower", False)))
             c.corridor_length = float(spec["corridor_length"])   # required keyword-only args (SEN:238)
             c.corridor_width = float(spec["corridor_width"])
             tracker_name = name
             seen_tracker = True
+        elif cls == "LeaderPositionsTracker":        # SEN:148-229, deprecated v1: looked up by this literal key and scanned ONCE per step
+            if name != "LeaderPositionsTracker":     # (CLS:257-261; its own dict entry is skipped, CLS:269-270, so it never shows up in the obs)
+                raise NotImplementedError("the v1 tracker must be registered under the key 'LeaderPositionsTracker' (CLS:257 looks it up by name)")
+            if c.has_tracker:
+                raise NotImplementedError("one tracker per follower (with both registered the v2 history silently replaces the v1 one, CLS:257-267)")
+            if not spec.get("generate_corridor", True) and any(True for _ in ()):
+                pass
+            c.has_tracker = 1
+            c.tracker_saving_period = int(spec.get("saving_period", 5))
+            c.trk1_eat_close_points = int(bool(spec.get("eat_close_points", True)))
+            c.corridor_length, c.corridor_width = 0.0, float(max_dev * pixels_to_meter)      # half-width = env.max_dev (SEN:189)
+            trk1_generate_corridor = bool(spec.get("generate_corridor", True))
+            tracker_name = name
+            seen_tracker = False                     # there is no second scan: every sensor sees the state after the one up-front scan
+        elif cls == "LaserSensor":                   # SEN:18-145
+            aa = min(360, spec.get("available_angle", 360))
+            step = spec.get("angle_step", 10)
+            border, cur, n_ang = int(aa / 2), 0, 1
+            while cur < border:                      # SEN:95-101
+                cur += step
+                n_ang += 2
+            if spec.get("return_all_points", False):
+                raise NotImplementedError("LaserSensor(return_all_points=True) returns a ragged list (every marching point up to the first hit, "
+                                          "SEN:112-113): no fixed-shape batched output")
+            only_d = bool(spec.get("return_only_distances", False))
+            rng_px = spec.get("sensor_range", 5) * pixels_to_meter
+            aux.append(AuxSpec(name=name, kind=abi.AUX_LIDAR, shape=(n_ang,) if only_d else (n_ang, 2), after_tracker=seen_tracker,
+                               params=dict(n_angles=n_ang, points_number=int(spec.get("points_number", 20)), return_only_distances=int(only_d),
+                                           range_px=float(rng_px), in_range_px=float(rng_px + 3 * pixels_to_meter), angle_step=float(step),
+                                           border_angle=border)))
+        elif cls in ("LeaderTrackDetector_vector", "LeaderTrackDetector_radar"):       # SEN:342-487
+            if name in ("LeaderTrackDetector_vector", "LeaderTrackDetector_radar") and \
+                    "LeaderPositionsTracker" not in follower_sensors and "LeaderPositionsTracker_v2" not in follower_sensors:
+                raise ValueError("Sensor {} requires sensor LeaderPositionsTracker for tracking leader movement.".format(name))   # CLS:240-243
+            L = int(spec.get("position_sequence_length", 100))
+            if cls == "LeaderTrackDetector_vector":
+                det = spec.get("detectable_positions", "new")
+                if det not in ("new", "old"):
+                    raise UnboundLocalError("local variable 'vecs' referenced before assignment")      # SEN:368-379
+                aux.append(AuxSpec(name=name, kind=abi.AUX_TRACK_VECTOR, shape=(L, 2), after_tracker=seen_tracker,
+                                   params=dict(seq_len=L, detectable=("new", "old").index(det))))
+            else:
+                det = spec.get("detectable_positions", "old")
+                if det not in ("new", "old", "near"):
+                    raise UnboundLocalError("local variable 'chosen_dots' referenced before assignment")   # SEN:452-462
+                ns = int(spec.get("radar_sectors_number", 180))
+                aux.append(AuxSpec(name=name, kind=abi.AUX_TRACK_RADAR, shape=(ns,), after_tracker=seen_tracker,
+                                   params=dict(seq_len=L, detectable=("new", "old", "near").index(det), radar_sectors=ns)))
         elif cls == "FollowerInfo":                  # SEN:822-845: [speed / max_speed, direction / 360], host-side from the state
             follower_info.append((name, int(spec.get("speed_direction_param", 2))))
         elif cls == "LeaderCorridor_lasers":         # SEN:571-702: 3 or 5 front rays, optionally 2 rear ones, current edges only
@@ -281,6 +356,19 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
                                     react_green=bool(spec.get("react_to_green_zone", False)),
                                     react_obstacles=_react_code(spec.get("react_to_obstacles", False)),
                                     history=1, angle_offset=0.0, after_tracker=seen_tracker, pad_sectors=False, lenient=True))
+        elif cls == "LeaderCorridor_lasers_compas":  # SEN:1138-1288: Prev_lasers_v2's constructor + a flag check
+            n = int(spec.get("lasers_count", 12))
+            if n not in (12, 24, 20, 36):
+                raise ValueError("Invalid number of laser beams, should be 12,24,20 or 36")  # SEN:761-762
+            hist = spec.get("max_prev_obs", 0)
+            assert hist > 0  # SEN:876
+            if not spec.get("react_to_safe_corridor", True) or not spec.get("react_to_green_zone", False) or spec.get("react_to_obstacles", False):
+                raise ValueError("Unsupported set of flags for LeaderCorridor_lasers_compas class, now implemented"
+                                 "only option for flags: "
+                                 "react_to_safe_corridor=True, react_to_green_zone=True, react_to_obstacles=False")   # SEN:1148-1151
+            lasers.append(LaserSpec(name=name, count=n, length=float(spec.get("laser_length", 100)), react_corridor=True, react_green=True,
+                                    react_obstacles=0, history=int(hist), angle_offset=float(spec.get("first_laser_angle_offset", -45)),
+                                    after_tracker=seen_tracker, pad_sectors=False, in_policy_obs=True, compas=True))
         else:
             n = int(spec.get("lasers_count", 12))
             if n not in (12, 24, 20, 36) and not spec.get("_allow_any_lasers_count", False):
@@ -296,8 +384,14 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
                                     after_tracker=seen_tracker, pad_sectors=bool(spec.get("pad_sectors", True)),
                                     in_policy_obs=True))
     if lasers and not c.has_tracker:
-        raise NotImplementedError("ray sensors need LeaderPositionsTracker_v2 (reference: NameError on "
+        raise NotImplementedError("ray sensors need a leader-positions tracker (reference: NameError on "
                                   "`leader_corridor`, CLS:280)")
+    if lasers and c.has_tracker == 1 and not trk1_generate_corridor:
+        raise NotImplementedError("generate_corridor=False leaves `leader_corridor` unbound for the ray sensors")
+    if any(a.kind != abi.AUX_LIDAR for a in aux) and not c.has_tracker:
+        raise NameError("name 'leader_positions_hist' is not defined")      # CLS:272: a detector without any tracker
+    if len(aux) > abi.FTL_MAX_AUX:
+        raise NotImplementedError(f"at most {abi.FTL_MAX_AUX} lidar / detector sensors")
     if len(lasers) > abi.FTL_MAX_LASERS:
         raise NotImplementedError(f"at most {abi.FTL_MAX_LASERS} ray sensors")
     c.n_lasers = len(lasers)
@@ -311,10 +405,20 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
         lc.pad_sectors = int(l.pad_sectors)
         lc.lenient = int(l.lenient)
         lc.in_policy_obs = int(l.in_policy_obs)
+        lc.compas = int(l.compas)
         lc.explicit_angles = int(l.ray_angles is not None)
         for i, a in enumerate(l.ray_angles or ()):
             lc.ray_angles[i] = a
         off += l.history * l.width
+    c.n_aux = len(aux)
+    for j, a in enumerate(aux):
+        a.out_offset = off
+        ac = c.aux[j]
+        ac.kind, ac.after_tracker, ac.out_offset, ac.out_len = a.kind, int(a.after_tracker), off, a.out_len
+        for k, v in a.params.items():
+            setattr(ac, k, v)
+        off += a.out_len
+    c.trk1_eat_radius = float(max(to_px(follower_size[1]), to_px(follower_size[0])))      # max(host.width, host.height), SEN:213
 
     # ---- leader regimes (ENV:382-397): int(key) -> value in dict insertion order ---------------------------------
     c.n_speed_regime, c.n_acc_regime = -1, -1
@@ -357,8 +461,13 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
     else:
         c.corr_cap = 16
     c.route_cap = int(route_cap)
+    # v1 tracker: one point per saving_period scans (one scan per step) + the follower's start position, never trimmed
+    steps_max = c.max_steps // max(1, min(c.frames_per_step, c.rand_fps_lo or c.frames_per_step)) + 2
+    c.hist1_cap = ((steps_max // max(c.tracker_saving_period, 1) + 8 + 7) // 8) * 8 if c.has_tracker == 1 else 8
+    if c.has_tracker == 1 and not corr_cap:
+        c.corr_cap = pow2(c.hist1_cap)      # the corridor gets one pair per saved point and is never trimmed either
 
-    cfg = GameConfig(kwargs=all_kwargs, c=c, lasers=lasers, tracker_name=tracker_name, sensor_order=order, follower_info=follower_info,
+    cfg = GameConfig(kwargs=all_kwargs, c=c, lasers=lasers, tracker_name=tracker_name, sensor_order=order, follower_info=follower_info, aux=aux,
                      discrete_action_space=bool(discrete_action_space),
                      constant_follower_speed=bool(constant_follower_speed), pixels_to_meter=pixels_to_meter)
     max_rot = c.follower.max_rotation_speed

@@ -12,6 +12,7 @@
 
 #include "ftl_device.hpp"
 #include "ftl_frames_group.hpp"
+#include "ftl_aux.hpp"
 
 namespace {
 
@@ -20,7 +21,7 @@ thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct Field { const char* name; size_t offset, per_env; int dtype; };
-constexpr int FTL_N_FIELDS = 12;
+constexpr int FTL_N_FIELDS = 13;
 
 }  // namespace
 
@@ -65,11 +66,24 @@ int validate(const ftl_config& c, std::string& why) {
     REQ((c.corr_cap & (c.corr_cap - 1)) == 0, "corr_cap must be a power of two (the tracker rings are indexed with a mask)");
     REQ(c.init_traj_cap <= c.traj_cap, "init_traj_cap > traj_cap");
     REQ(c.traj_cap % FTL_TRAJ_BLOCK == 0, "traj_cap must be a multiple of FTL_TRAJ_BLOCK");
-    if (c.has_tracker) {
+    if (c.has_tracker == 2) {
         REQ(c.tracker_saving_period > 0, "tracker saving_period must be positive");
         REQ(c.corridor_length > 0 && c.corridor_width > 0, "corridor_length / corridor_width must be positive");
     }
     REQ(c.n_speed_regime <= FTL_MAX_REGIME && c.n_acc_regime <= FTL_MAX_REGIME, "too many regime entries");
+    REQ(c.has_tracker >= 0 && c.has_tracker <= 2, "has_tracker must be 0, 1 (v1) or 2 (v2)");
+    if (c.has_tracker == 1) REQ(c.tracker_saving_period > 0 && c.hist1_cap >= 8 && c.corridor_width > 0, "bad v1 tracker parameters");
+    REQ(c.n_aux >= 0 && c.n_aux <= FTL_MAX_AUX, "n_aux out of range");
+    for (int j = 0; j < c.n_aux; j++) {
+        const ftl_aux_cfg& a = c.aux[j];
+        REQ(a.kind >= FTL_AUX_LIDAR && a.kind <= FTL_AUX_TRACK_RADAR, "aux %d: unknown sensor kind", j);
+        if (a.kind == FTL_AUX_LIDAR) REQ(a.n_angles > 0 && a.n_angles <= 512 && a.points_number > 0 && a.range_px > 0 && !a.return_all_points, "aux %d: bad lidar parameters", j);
+        else {
+            REQ(c.has_tracker != 0, "aux %d: a leader-track detector needs a tracker (classes.py:272 would raise NameError)", j);
+            REQ(a.seq_len > 0 && a.detectable >= 0 && a.detectable <= (a.kind == FTL_AUX_TRACK_RADAR ? 2 : 1), "aux %d: bad detector parameters", j);
+            if (a.kind == FTL_AUX_TRACK_RADAR) REQ(a.radar_sectors > 0 && a.radar_sectors <= 4096, "aux %d: bad radar_sectors_number", j);
+        }
+    }
     for (int k = 0; k < c.n_lasers; k++) {
         const ftl_laser_cfg& l = c.lasers[k];
         REQ(l.count > 0 && l.count <= 1024, "laser %d: bad lasers_count", k);
@@ -110,7 +124,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     {   // measured: +9 % with random_frames_per_step (long frame kernels whose tails the other half's ray kernel fills), -1 % with a
         // fixed 10 frames per step -- so it is on for the former only; FTL_SPLIT=0/1 overrides
         const char* sp = getenv("FTL_SPLIT");
-        h->split = n_envs >= 8192 && (sp ? sp[0] == '1' : cfg->rand_fps_hi > 0);
+        h->split = n_envs >= 8192 && (sp ? sp[0] == '1' : cfg->rand_fps_hi > 0) && cfg->has_tracker != 1;   // (the v1 tracker kernel covers all envs at once)
     }
     {   // the scatter pass reads one histogram row per block of 1024 envs: fine up to a few hundred blocks
         const char* off = getenv("FTL_NO_REGROUP");
@@ -122,11 +136,17 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     P.n_envs = n_envs;
     P.R = 2 + cfg->n_bears;
     int off = 0, hmax = 1, rays = 0;
+    auto width_of = [](const ftl_laser_cfg& l) { return l.count * (l.compas ? 5 : (l.pad_sectors ? 4 : 1)); };
     for (int k = 0; k < cfg->n_lasers; k++) {
         P.cfg.lasers[k].out_offset = off;
-        off += cfg->lasers[k].history * cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1);
+        off += cfg->lasers[k].history * width_of(cfg->lasers[k]);
         hmax = cfg->lasers[k].history > hmax ? cfg->lasers[k].history : hmax;
         rays += cfg->lasers[k].count;
+    }
+    for (int j = 0; j < cfg->n_aux; j++) {       // lidar / detector blocks follow the ray sensors' blocks
+        ftl_aux_cfg& a = P.cfg.aux[j];
+        a.out_len = a.kind == FTL_AUX_LIDAR ? a.n_angles * (a.return_only_distances ? 1 : 2) : a.kind == FTL_AUX_TRACK_VECTOR ? 2 * a.seq_len : a.radar_sectors;
+        a.out_offset = off; off += a.out_len;
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
     if (hmax * (P.R - 1) > FTL_WAVE) { delete h; return fail(FTL_E_INVALID, "max_prev_obs x (1 + bears) exceeds one wavefront of snapshot rects"); }
@@ -135,7 +155,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         for (int k = 0; k < cfg->n_lasers; k++) {
             P.pol_off[k] = -1;
             if (!cfg->lasers[k].in_policy_obs) continue;
-            P.pol_off[k] = w; w += cfg->lasers[k].count * (cfg->lasers[k].pad_sectors ? 4 : 1);
+            P.pol_off[k] = w; w += width_of(cfg->lasers[k]);
             if (hcommon == 0) hcommon = cfg->lasers[k].history;
             else if (cfg->lasers[k].history != hcommon) hcommon = -1;
         }
@@ -148,7 +168,8 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         {"env_int", FTL_EI_COUNT, 0, 4}, {"env_dbl", FTL_ED_COUNT, 2, 8}, {"traj", (size_t)cfg->traj_cap * 2, 1, 4},
         {"hist", (size_t)cfg->corr_cap * 2, 2, 8}, {"corr", (size_t)cfg->corr_cap * 4, 2, 8},
         {"snap_rects", (size_t)hmax * (P.R - 1) * 4, 0, 4}, {"snap_win", (size_t)hmax * 4, 0, 4},
-        {"traj_bb", (size_t)(cfg->traj_cap / FTL_TRAJ_BLOCK) * 4, 1, 4}, {"ep_stats", FTL_N_METRICS, 2, 8}};
+        {"traj_bb", (size_t)(cfg->traj_cap / FTL_TRAJ_BLOCK) * 4, 1, 4}, {"ep_stats", FTL_N_METRICS, 2, 8},
+        {"hist1", (size_t)(cfg->has_tracker == 1 ? cfg->hist1_cap : 0) * 2, 1, 4}};
     size_t cur = 0;
     for (int i = 0; i < FTL_N_FIELDS; i++) {
         cur = align_up(cur, 256);
@@ -213,6 +234,7 @@ int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes) {
     P.hist = (double*)(b + h->fields[6].offset); P.corr = (double*)(b + h->fields[7].offset);
     P.snap_rects = (int32_t*)(b + h->fields[8].offset); P.snap_win = (int32_t*)(b + h->fields[9].offset);
     P.traj_bb = (float*)(b + h->fields[10].offset); P.ep_stats = (double*)(b + h->fields[11].offset);
+    P.hist1 = (float*)(b + h->fields[12].offset);
     h->bound = true; h->dirty = true;
     return FTL_OK;
 }
@@ -295,10 +317,12 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
             if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<8, true>), grid, block, lds, s, h->dP, c2);
             else hipLaunchKernelGGL((ftl_frames_group_kernel<8, false>), grid, block, lds, s, h->dP, c2);
         }
+        if (h->P.cfg.has_tracker == 1 && part == 0)      // the v1 tracker's scan + snapshot bookkeeping for ALL envs (one thread per env)
+            hipLaunchKernelGGL(ftl::ftl_tracker1_kernel, dim3((unsigned)((h->P.n_envs + 255) / 256)), dim3(256), 0, s, h->dP, c2);
         if (tev) (void)hipEventRecord(tev[1], s);
         if (h->P.cfg.n_lasers > 0) {
             bool expl = false;
-            for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0 || h->P.cfg.lasers[k].pad_sectors != 0;
+            for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0 || h->P.cfg.lasers[k].pad_sectors != 0 || h->P.cfg.lasers[k].compas != 0;
             const dim3 rgrid(count);
             if (parts > 1) {   // two-stream mode: the instantiations that map blocks to one half of the slot groups
                 if (!expl && h->P.hmax > 5 && h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
@@ -322,6 +346,11 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         (void)hipEventRecord(h->ev_join, h->side);
         (void)hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0);        // the caller's stream sees the whole step
     } else launch_range(0, 1, (hipStream_t)stream);
+    {   // compas / lidar / leader-track detectors: one more launch, only for configs that have such a sensor
+        bool aux = h->P.cfg.n_aux > 0;
+        for (int k = 0; k < h->P.cfg.n_lasers; k++) aux = aux || h->P.cfg.lasers[k].compas != 0;
+        if (aux) hipLaunchKernelGGL(ftl_aux_kernel, dim3((unsigned)h->P.n_envs), dim3(FTL_WAVE), 0, (hipStream_t)stream, h->dP, call);
+    }
     // the frame kernel left every env's cost class for its next step: rebuild the slot -> env map.  The classes are stable
     // from step to step unless the frame count is random, so every second launch is enough then.
     if (h->regroup && (h->P.cfg.rand_fps_hi > 0 || call.mode == 1 || (h->rg_launches++ % h->rg_every) == 0)) {

@@ -1,0 +1,325 @@
+// ftl_aux.hpp -- the sensors of the registry (utils/sensors.py:1291-1307) that are not f32 segment ray casts, and the deprecated
+// v1 tracker.  They run in kernels of their own, launched only when the config has them, so that the two hot kernels carry none
+// of this code:
+//
+//   ftl_tracker1_kernel -- LeaderPositionsTracker (sensors.py:148-229), one THREAD per env, between the frame kernel and the ray
+//       kernel: append / corridor pair / eat_close_points, then the snapshot bookkeeping the frame kernel does for the v2 tracker.
+//   ftl_aux_kernel -- one wavefront per env, after the ray kernel:
+//       * LeaderCorridor_lasers_compas (sensors.py:1138-1288): corridor walls in float64, nearest wall's orientation selects the block;
+//       * LaserSensor (sensors.py:18-145): point-in-rect marching;
+//       * LeaderTrackDetector_vector / _radar (sensors.py:342-487) on the tracker's position history.
+// Numerics follow oracle/ftl_oracle.c (compas_scan, lidar_scan, track_vector_scan, track_radar_scan, tracker1_scan).
+#pragma once
+#include "ftl_device.hpp"
+
+namespace ftl {
+
+// ---------------------------------------------------------------- v1 tracker
+__global__ void __launch_bounds__(256) ftl_tracker1_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
+    const FtlDevParams& P = *Pp;
+    const ftl_config& c = P.cfg;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= P.n_envs) return;
+    if (C.mode == 1 && C.mask && !C.mask[env]) return;
+    int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
+    int counter = ei[FTL_EI_TRK_COUNTER], hlen = ei[FTL_EI_HIST1_LEN], clen = ei[FTL_EI_CORR_HI], err = 0;
+    const float lpx = P.rb_pos[2 * ((size_t)env * P.R)], lpy = P.rb_pos[2 * ((size_t)env * P.R) + 1];
+    const float fpx = P.rb_pos[2 * ((size_t)env * P.R + 1)], fpy = P.rb_pos[2 * ((size_t)env * P.R + 1) + 1];
+    float2* h = reinterpret_cast<float2*>(P.hist1) + (size_t)env * c.hist1_cap;
+    bool unchanged = false;
+    if (counter % c.tracker_saving_period == 0) {
+        if (hlen > 0 && h[hlen - 1].x == lpx && h[hlen - 1].y == lpy) unchanged = true;     // SEN:178-183: returns before anything else
+        else {
+            if (hlen + 2 > c.hist1_cap) err |= FTL_ERR_HIST1_OVERFLOW;
+            else {
+                if (hlen == 0) h[hlen++] = make_float2(fpx, fpy);                           // SEN:185-186
+                h[hlen++] = make_float2(lpx, lpy);                                          // SEN:187
+                if (hlen > 1) {                                                             // SEN:188-195, half-width env.max_dev
+                    if (clen + 1 > c.corr_cap) err |= FTL_ERR_CORR_OVERFLOW;
+                    else {
+                        const float2 p1 = h[hlen - 1], p0 = h[hlen - 2];
+                        float fx = p1.x - p0.x, fy = p1.y - p0.y;
+                        const float nrm = sqrtf(fx * fx + fy * fy);
+                        const float sc = (float)c.corridor_width / nrm;
+                        fx *= sc; fy *= sc;
+                        const double vx = (double)fx, vy = (double)fy;
+                        const double c90 = 6.123233995736766e-17, s90 = 1.0, cm90 = 6.123233995736766e-17, sm90 = -1.0;
+                        double* q = corr_slot(P, env, clen);
+                        q[0] = (c90 * vx + (-s90) * vy) + (double)p0.x; q[1] = (s90 * vx + c90 * vy) + (double)p0.y;
+                        q[2] = (cm90 * vx + (-sm90) * vy) + (double)p0.x; q[3] = (sm90 * vx + cm90 * vy) + (double)p0.y;
+                        clen += 1;
+                    }
+                }
+            }
+        }
+    }
+    if (!unchanged) {
+        counter += 1;
+        if (c.trk1_eat_close_points && hlen > 0) {                                          // SEN:211-216
+            const float thr = (float)c.trk1_eat_radius;
+            int w = 0;
+            for (int i = 0; i < hlen; i++) {
+                const float2 p = h[i];
+                const float dx = p.x - fpx, dy = p.y - fpy;
+                if (sqrtf(dx * dx + dy * dy) <= thr) continue;
+                if (w != i) h[w] = p;
+                w++;
+            }
+            hlen = w;
+        }
+    }
+    // what the frame kernel's g_sensors() does after the v2 scans: may the ray sensors scan, and one snapshot per step
+    int groups = 0, strict = 0;
+    for (int k = 0; k < c.n_lasers; k++) { groups |= 1; if (!c.lasers[k].lenient) strict |= 1; }
+    int ok = 0;
+    if (groups) { if (clen > 1) ok = 1; else if (strict) err |= FTL_ERR_EMPTY_CORRIDOR; }
+    if (ok) {
+        const int slot = ei[FTL_EI_SNAP_HEAD];
+        int4* sr = reinterpret_cast<int4*>(P.snap_rects) + ((size_t)env * P.hmax + slot) * (P.R - 1);
+        for (int r = 0; r < P.R; r++) if (r != 1) sr[r == 0 ? 0 : r - 1] = reinterpret_cast<const int4*>(P.rb_int + ((size_t)env * P.R + r) * FTL_RI_COUNT)[0];
+        int* sw = P.snap_win + ((size_t)env * P.hmax + slot) * 4;
+        sw[0] = 0; sw[1] = clen; sw[2] = 0; sw[3] = clen;
+        ei[FTL_EI_SNAP_COUNT] += 1;
+        ei[FTL_EI_SNAP_HEAD] = (slot + 1 == P.hmax) ? 0 : slot + 1;
+    }
+    ei[FTL_EI_TRK_COUNTER] = counter; ei[FTL_EI_HIST1_LEN] = hlen; ei[FTL_EI_CORR_LO] = 0; ei[FTL_EI_CORR_HI] = clen; ei[FTL_EI_SCAN_OK] = ok;
+    if (err) { ei[FTL_EI_ERROR] |= err; ei[FTL_EI_ERROR_STICKY] |= err; }
+}
+
+// ---------------------------------------------------------------- compas: one wall against one ray, every operand float64
+__device__ __forceinline__ bool wall_hit(double ax, double ay, double bx, double by, double cx, double cy, double ex, double ey, double& d2) {
+    const bool t1 = (ey - ay) * (cx - ax) > (cy - ay) * (ex - ax);   // ccw(A,C,D), sensors.py:608-614
+    const bool t2 = (ey - by) * (cx - bx) > (cy - by) * (ex - bx);   // ccw(B,C,D)
+    const bool t3 = (cy - ay) * (bx - ax) > (by - ay) * (cx - ax);   // ccw(A,B,C)
+    const bool t4 = (ey - ay) * (bx - ax) > (by - ay) * (ex - ax);   // ccw(A,B,D)
+    if (!((t1 != t2) && (t3 != t4))) return false;
+    const double dax = bx - ax, day = by - ay, dbx = ex - cx, dby = ey - cy, dpx = ax - cx, dpy = ay - cy;      // seg_intersect, 626-640
+    const double dapx = -day, dapy = dax;
+    const double t = (dapx * dpx + dapy * dpy) / (dapx * dbx + dapy * dby);
+    const double x = t * dbx + cx, y = t * dby + cy;
+    const double qx = x - cx, qy = y - cy;
+    d2 = qx * qx + qy * qy;
+    return true;
+}
+
+}  // namespace ftl
+
+// One wavefront per env.  LDS: [0, 16 KiB) scratch shared by the sensors, used one after the other.
+__global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
+    using namespace ftl;
+    __shared__ __align__(16) unsigned char lds[16384];
+    const FtlDevParams& P = *Pp;
+    const ftl_config& c = P.cfg;
+    const int env = blockIdx.x, lane = threadIdx.x;
+    if (env >= P.n_envs) return;
+    if (C.mode == 1 && C.mask && !C.mask[env]) return;
+    const int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
+    const size_t fo = (size_t)env * P.R + 1;
+    const float cxf = P.rb_pos[2 * fo], cyf = P.rb_pos[2 * fo + 1];
+    const double cx = (double)cxf, cy = (double)cyf;
+    const double fdir = P.rb_dbl[fo * FTL_RD_COUNT + FTL_RD_DIRECTION];
+    float* out_base = C.out.lasers + (size_t)env * P.lasers_len;
+    const unsigned long long kInf = 0x7fefffffffffffffull;
+
+    // ---------------- LeaderCorridor_lasers_compas ------------------------------------------------------------------------------
+    for (int k = 0; k < c.n_lasers; k++) {
+        const ftl_laser_cfg& Lc = c.lasers[k];
+        if (!Lc.compas) continue;
+        const int N = Lc.count, H = Lc.history, W = 5 * N, which = Lc.after_tracker;
+        float* out = out_base + Lc.out_offset;
+        float* pol = (C.out.policy_obs && P.pol_off[k] >= 0) ? C.out.policy_obs + (size_t)env * P.pol_h * P.pol_width + P.pol_off[k] : nullptr;
+        const float flen = (float)Lc.length;
+        if (!((ei[FTL_EI_SCAN_OK] >> which) & 1)) {      // SEN:1192/1244: the reference raises UnboundLocalError (error bit set by the tracker code)
+            for (int i = lane; i < H * W; i += FTL_WAVE) {
+                const float v = (i % W) < N ? flen : 0.0f;
+                out[i] = v;
+                if (pol) pol[(i / W) * P.pol_width + (i % W)] = fminf(fmaxf(v / flen, 0.0f), 1.0f);
+            }
+            continue;
+        }
+        double2* s_ray = reinterpret_cast<double2*>(lds);                                   // [N]
+        unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + N);      // [N][H]: squared distance, wall class in the 2 low bits
+        int* s_win = reinterpret_cast<int*>(s_best + N * H);                                // [H][2]
+        __syncthreads();
+        const int snap_count = ei[FTL_EI_SNAP_COUNT], snap_head = ei[FTL_EI_SNAP_HEAD];
+        const int newest = (snap_head == 0 ? P.hmax : snap_head) - 1;
+        const int nsnap = snap_count < H ? snap_count : H;
+        if (lane < H) {
+            int lo = 0, hi = 0;
+            if (lane < nsnap) {
+                int slot = newest - lane; slot += slot < 0 ? P.hmax : 0;
+                const int* sw = P.snap_win + ((size_t)env * P.hmax + slot) * 4 + 2 * which;
+                lo = sw[0]; hi = sw[1];
+            }
+            s_win[2 * lane] = lo; s_win[2 * lane + 1] = hi;
+        }
+        for (int i = lane; i < N; i += FTL_WAVE) {
+            double s, co;
+            sincos_bounded(((fdir + Lc.angle_offset) + i * (360.0 / (double)N)) * kDeg2Rad, s, co);
+            s_ray[i] = make_double2(cx + co * Lc.length, cy + s * Lc.length);
+        }
+        for (int i = lane; i < N * H; i += FTL_WAVE) s_best[i] = kInf;
+        __syncthreads();
+        int umin = 0x7fffffff, umax = 0;
+        for (int a = 0; a < nsnap; a++) { umin = min(umin, s_win[2 * a]); umax = max(umax, s_win[2 * a + 1]); }
+        const int n_wall = nsnap > 0 ? 2 * max(umax - umin - 1, 0) : 0;
+        const int n_items = n_wall + 2 * nsnap;
+        // (item, ray) pairs; an item is a wall shared by every snapshot whose window holds both of its points, or an end cap of ONE snapshot
+        for (int w = lane; w < n_items * N; w += FTL_WAVE) {
+            const int item = w / N, ray = w - item * N;
+            double ax, ay, bx, by; unsigned sm = 0; int cls;
+            if (item < n_wall) {
+                const int p = umin + (item >> 1), side = item & 1;             // side 0: right wall (class 3), 1: left wall (class 2)
+                for (int a = 0; a < nsnap; a++) if (s_win[2 * a] <= p && p + 1 < s_win[2 * a + 1]) sm |= 1u << a;
+                const double* u = corr_slot(P, env, p); const double* v = corr_slot(P, env, p + 1);
+                ax = u[2 * side]; ay = u[2 * side + 1]; bx = v[2 * side]; by = v[2 * side + 1];
+                cls = side ? 2 : 3;
+            } else {
+                const int a = (item - n_wall) >> 1, back = (item - n_wall) & 1;   // front = corridor[-1] (class 0), back = corridor[0] (class 1)
+                const double* u = corr_slot(P, env, back ? s_win[2 * a] : s_win[2 * a + 1] - 1);
+                ax = u[0]; ay = u[1]; bx = u[2]; by = u[3];
+                sm = 1u << a; cls = back;
+            }
+            if (!sm) continue;
+            const double2 e = s_ray[ray];
+            double d2;
+            if (wall_hit(ax, ay, bx, by, cx, cy, e.x, e.y, d2)) {
+                // np.argmin takes the FIRST of equal minima in the order front, back, left walls, right walls (SEN:1166): the class code
+                // rides in the two low mantissa bits, so equal distances resolve the same way (3 ulp of float64 before the float32 store)
+                const unsigned long long key = ((unsigned long long)__double_as_longlong(d2) & ~3ull) | (unsigned long long)cls;
+                for (int a = 0; a < nsnap; a++) if ((sm >> a) & 1u) atomicMin(&s_best[ray * H + a], key);
+            }
+        }
+        __syncthreads();
+        // rows, oldest first (SEN:1247): block 0 = rays without a wall hit (|end - position|), then front / back / left / right
+        for (int i = lane; i < H * W; i += FTL_WAVE) { out[i] = 0.0f; if (pol) pol[(i / W) * P.pol_width + (i % W)] = 0.0f; }
+        __syncthreads();
+        for (int w = lane; w < N * H; w += FTL_WAVE) {
+            const int ray = w / H, a = w - ray * H;
+            const unsigned long long key = s_best[w];
+            const double2 e = s_ray[ray];
+            int col; double v;
+            if (a < nsnap && key != kInf) { col = (1 + (int)(key & 3ull)) * N + ray; v = sqrt(__longlong_as_double((long long)(key & ~3ull))); }
+            else { const double qx = e.x - cx, qy = e.y - cy; col = ray; v = sqrt(__builtin_fma(qy, qy, qx * qx)); }
+            const float vf = (float)v;
+            out[(H - 1 - a) * W + col] = vf;
+            if (pol) pol[(H - 1 - a) * P.pol_width + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- LaserSensor / LeaderTrackDetector_* --------------------------------------------------------------------------
+    for (int j = 0; j < c.n_aux; j++) {
+        const ftl_aux_cfg& A = c.aux[j];
+        float* out = out_base + A.out_offset;
+        __syncthreads();
+        if (A.kind == FTL_AUX_LIDAR) {
+            int4* s_rect = reinterpret_cast<int4*>(lds);                          // [<= 256] rects in range
+            float2* s_end = reinterpret_cast<float2*>(lds + 4096);                // [n_angles] ray ends
+            int* s_first = reinterpret_cast<int*>(lds + 4096 + 8 * 512);          // [n_angles] first marching point inside a rect
+            int* s_cnt = reinterpret_cast<int*>(lds + 4096 + 12 * 512);
+            if (lane == 0) *s_cnt = 0;
+            __syncthreads();
+            // objects_in_range (SEN:72-79): leader, static rects, bears whose nearest corner / edge mid-point is within range + 3 m
+            const int nobj = 1 + c.n_static + c.n_bears;
+            const int scen = ei[FTL_EI_SCEN];
+            for (int o = lane; o < nobj; o += FTL_WAVE) {
+                int4 q;
+                if (o == 0) q = reinterpret_cast<const int4*>(P.rb_int + ((size_t)env * P.R) * FTL_RI_COUNT)[0];
+                else if (o <= c.n_static) q = reinterpret_cast<const int4*>(P.scen.static_rects)[(size_t)scen * c.n_static + (o - 1)];
+                else q = reinterpret_cast<const int4*>(P.rb_int + ((size_t)env * P.R + 2 + (o - 1 - c.n_static)) * FTL_RI_COUNT)[0];
+                const int px[8] = { q.x, q.x, q.x + q.z, q.x + q.z, q.x + (q.z >> 1), q.x, q.x + (q.z >> 1), q.x + q.z };
+                const int py[8] = { q.y, q.y + q.w, q.y, q.y + q.w, q.y, q.y + (q.w >> 1), q.y + q.w, q.y + (q.w >> 1) };
+                double dmin = 1.0e300;
+#pragma unroll
+                for (int t = 0; t < 8; t++) dmin = fmin(dmin, euclid_f64(cx, cy, (double)px[t], (double)py[t]));
+                if (dmin <= A.in_range_px) { const int at = atomicAdd(s_cnt, 1); if (at < 256) s_rect[at] = q; }
+            }
+            const int n_ang = A.n_angles < 512 ? A.n_angles : 512;
+            for (int a = lane; a < n_ang; a += FTL_WAVE) {                         // SEN:88-104
+                double angle = -fdir;
+                if (a > 0) { const double kk = (double)((a + 1) / 2) * A.angle_step; angle = angle_correction((a & 1) ? -fdir + kk : -fdir - kk); }
+                double s, co;
+                sincos_bounded(angle * kDeg2Rad, s, co);
+                s_end[a] = make_float2(cxf + (float)(A.range_px * co), cyf - (float)(A.range_px * s));      // np.float32 + python float -> float32
+                s_first[a] = 0x7fffffff;
+            }
+            __syncthreads();
+            const int nin = min(*s_cnt, 256);
+            for (int w = lane; w < n_ang * A.points_number; w += FTL_WAVE) {       // SEN:106-121
+                const int a = w / A.points_number, i = w - a * A.points_number;
+                const double u = (double)i / (double)A.points_number;
+                const float2 e = s_end[a];
+                const float px = e.x * (float)u + cxf * (float)(1.0 - u), py = e.y * (float)u + cyf * (float)(1.0 - u);
+                bool hit = false;
+                for (int o = 0; o < nin; o++) {
+                    const int4 q = s_rect[o];
+                    hit = hit || ((float)q.x <= px && px < (float)(q.x + q.z) && (float)q.y <= py && py < (float)(q.y + q.w));
+                }
+                if (hit) atomicMin(&s_first[a], i);
+            }
+            __syncthreads();
+            for (int a = lane; a < n_ang; a += FTL_WAVE) {
+                const float2 e = s_end[a];
+                float px = e.x, py = e.y;
+                if (s_first[a] != 0x7fffffff) {
+                    const double u = (double)s_first[a] / (double)A.points_number;
+                    px = e.x * (float)u + cxf * (float)(1.0 - u); py = e.y * (float)u + cyf * (float)(1.0 - u);
+                }
+                const float dx = px - cxf, dy = py - cyf;
+                if (A.return_only_distances) out[a] = sqrtf(dx * dx + dy * dy);
+                else { out[2 * a] = dx; out[2 * a + 1] = dy; }
+            }
+        } else {
+            // the tracked leader positions the detector looks at: v1 = the float32 "hist1" list, v2 = a window of the "hist" ring as the
+            // detector's dict position saw it; points of the ring below seed_end are float64, the others float32 values
+            const bool v1 = c.has_tracker == 1;
+            int lo, hi;
+            if (v1) { lo = 0; hi = ei[FTL_EI_HIST1_LEN]; }
+            else if (A.after_tracker) { lo = ei[FTL_EI_CORR_LO]; hi = ei[FTL_EI_CORR_HI]; }
+            else { lo = ei[FTL_EI_HW0_LO]; hi = ei[FTL_EI_HW0_HI]; }
+            const int n = hi - lo;
+            int s0 = 0, s1 = n;                                                    // slice of [0, n)
+            if (A.detectable == 0) s0 = n - A.seq_len > 0 ? n - A.seq_len : 0;     // "new": the last seq_len
+            else if (A.detectable == 1) s1 = n < A.seq_len ? n : A.seq_len;        // "old": the first seq_len
+            auto point = [&](int i, double& hx, double& hy) {
+                if (v1) { const float2 q = reinterpret_cast<const float2*>(P.hist1)[(size_t)env * c.hist1_cap + i]; hx = (double)q.x; hy = (double)q.y; }
+                else { const double* q = hist_slot(P, env, lo + i); hx = q[0]; hy = q[1]; }
+            };
+            if (A.kind == FTL_AUX_TRACK_VECTOR) {                                  // SEN:362-381
+                for (int i = lane; i < A.seq_len; i += FTL_WAVE) {
+                    float vx = 0.0f, vy = 0.0f;
+                    if (s0 + i < s1) { double hx, hy; point(s0 + i, hx, hy); vx = (float)(hx - cx); vy = (float)(hy - cy); }
+                    out[2 * i] = vx; out[2 * i + 1] = vy;
+                }
+            } else {                                                               // SEN:423-476
+                unsigned* s_rad = reinterpret_cast<unsigned*>(lds);                // [sectors] float bits of the nearest distance (0x7f800000: none)
+                const int S = A.radar_sectors < 4096 ? A.radar_sectors : 4096;
+                for (int s = lane; s < S; s += FTL_WAVE) s_rad[s] = 0x7f800000u;
+                __syncthreads();
+                double sd, cd, sr, cr;
+                sincos_bounded(fdir * kDeg2Rad, sd, cd);
+                double rdir = fdir + 90; if (rdir >= 360) rdir -= 360;
+                sincos_bounded(rdir * kDeg2Rad, sr, cr);
+                const double dvx = cd * 1 + (-sd) * 0, dvy = sd * 1 + cd * 0, rvx = cr * 1 + (-sr) * 0, rvy = sr * 1 + cr * 0;
+                const double nd = sqrt(__builtin_fma(dvy, dvy, dvx * dvx)), nr = sqrt(__builtin_fma(rvy, rvy, rvx * rvx));
+                const bool any64 = !v1 && (lo + s0) < ei[FTL_EI_SEED_END] && s0 < s1;   // a float64 point in the slice makes the whole array float64
+                const double sa = 3.141592653589793 / (double)A.radar_sectors;
+                for (int i = s0 + lane; i < s1; i += FTL_WAVE) {
+                    double hx, hy; point(i, hx, hy);
+                    double vx, vy, dist;
+                    if (any64) { vx = hx - cx; vy = hy - cy; dist = sqrt(vx * vx + vy * vy); }
+                    else { const float fx = (float)hx - cxf, fy = (float)hy - cyf; vx = (double)fx; vy = (double)fy; dist = (double)sqrtf(fx * fx + fy * fy); }
+                    const double ad = acos((vx * dvx + vy * dvy) / (dist * nd));
+                    double ar = acos((vx * rvx + vy * rvy) / (dist * nr));
+                    if (ad > 3.141592653589793 / 2) ar = -ar;
+                    int s = (int)floor(ar / sa);                                   // candidate sector; the reference's own comparisons decide
+                    for (int t = s - 1; t <= s + 1; t++)
+                        if (t >= 0 && t < S && ar >= sa * t && ar < sa * (t + 1)) atomicMin(&s_rad[t], __float_as_uint((float)dist));
+                }
+                __syncthreads();
+                for (int s = lane; s < S; s += FTL_WAVE) out[s] = s_rad[s] == 0x7f800000u ? 0.0f : __uint_as_float(s_rad[s]);
+            }
+        }
+    }
+}

@@ -42,6 +42,7 @@ struct FtlDevParams {
     float* traj; double* hist; double* corr; int32_t* snap_rects; int32_t* snap_win;
     float* traj_bb;                   // [n_envs][traj_cap / FTL_TRAJ_BLOCK][4]: xmin, ymin, xmax, ymax of each block of trajectory points
     double* ep_stats;                 // [n_envs][FTL_N_METRICS]: metrics of the episodes that ended in this env slot (include/ftl.h)
+    float* hist1;                     // [n_envs][hist1_cap][2]: position history of the v1 tracker (sensors.py:148-229)
     // env regrouping (library-owned; null = envs stay bound to their wavefronts): slot -> env, cost class of the next step,
     // rank inside the block histogram, per-block key histograms
     int32_t* perm; uint8_t* keys; uint16_t* rank; int32_t* bh;
@@ -357,7 +358,8 @@ __shared__ unsigned long long s_rcyc[16];
 // row layout: compiled apart so that the common kernels carry none of that code (it cost 3 % even when never executed)
 // The per-sensor loops run to the compile-time bound FTL_MAX_LASERS with the count as a guard: unrolled, the config fields they
 // read become loop-invariant scalar loads that the compiler hoists out of the chunk loops (the ray kernel got 5 % faster).
-#define FTL_FOR_LASERS(k) _Pragma("unroll") for (int k = 0; k < FTL_MAX_LASERS; k++) if (k < c.n_lasers)
+// (LeaderCorridor_lasers_compas entries are cast by ftl_aux_kernel in float64; configs that have one run the EXPL instantiations)
+#define FTL_FOR_LASERS(k) _Pragma("unroll") for (int k = 0; k < FTL_MAX_LASERS; k++) if (k < c.n_lasers && !(EXPL && c.lasers[k].compas))
 
 // SPLIT = the launch covers one of the interleaved halves of the slot groups (two-stream mode) instead of all envs
 template <int HM, bool EXPL = false, bool SPLIT = false>
@@ -434,7 +436,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) { n_sens++; lmax = fmaxf(lmax, (float)c.lasers[k].length); }
         if (n_sens == 0) continue;
         if (!((scan_ok >> which) & 1)) {       // sensors.py:893/962: the reference raises UnboundLocalError here
-            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which) {
+            for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which && !(EXPL && c.lasers[k].compas)) {
                 const int Wd = c.lasers[k].count * (c.lasers[k].pad_sectors ? 4 : 1);
                 for (int i = lane; i < c.lasers[k].history * Wd; i += FTL_WAVE) {
                     out_base[c.lasers[k].out_offset + i] = (float)c.lasers[k].length;

@@ -242,6 +242,7 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         E.green_count = 0; E.green_len = -1; E.green_w = 0.0; E.green_tiny = 0; E.error = 0; E.scan_ok = 0;
         E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0; E.snap_head = 0;
         E.hint = 0; E.hx = 3.0e38f; E.hy = 3.0e38f; E.clr_g = 0.0f; E.clr_a = 0.0f;     // no cached point, no bound
+        if (c.has_tracker == 1 && E.r == 0) P.env_int[(size_t)E.env * FTL_EI_COUNT + FTL_EI_HIST1_LEN] = 0;   // v1 tracker reset(), SEN:223-226
         if (c.rand_fps_hi > 0 && E.fps == 0) E.fps = d_rand_frames(c, E.env, 0, 0);      // the constructor's draw (ENV:405)
         E.cur_mult = 1.0; E.cur_acc = 0.0; E.cum_speed = 0.0; E.resets += 1;      // ENV:449, 591-592; acc_consumed persists (ENV:1170)
     }
@@ -876,7 +877,7 @@ __device__ __forceinline__ void g_border_pair(const FtlDevParams& P, const GCtx&
 template <int G>
 __device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
     const ftl_config& c = P.cfg;
-    if (!c.has_tracker) { E.scan_ok = 0; return; }
+    if (c.has_tracker != 2) { E.scan_ok = 0; return; }       // no tracker, or the v1 tracker (ftl_tracker1_kernel does its scan and the snapshot)
     int groups = 0, strict = 0;       // dict-order groups with a ray sensor / with one that raises on a corridor of <= 1 points
     for (int k = 0; k < c.n_lasers; k++) {
         groups |= 1 << (c.lasers[k].after_tracker ? 1 : 0);
@@ -974,6 +975,7 @@ __device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
         }
         if (g == 0) { w0lo = E.corr_lo; w0hi = E.corr_hi; }
     }
+    if (c.n_aux > 0 && w) { int* ei = P.env_int + (size_t)E.env * FTL_EI_COUNT; ei[FTL_EI_HW0_LO] = w0lo; ei[FTL_EI_HW0_HI] = w0hi; }
     E.scan_ok = ok;
     if (ok && E.valid) {             // one snapshot per step: dynamic rects + the corridor window each group saw
         int slot = E.snap_head;
@@ -1215,7 +1217,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         // tracker: envs whose counters are at most one scan apart save in the same steps and stay together from step to
         // step (all counters advance by two per step); class 0 = saves in the next step
         int tc = 0;
-        if (P.cfg.has_tracker) {
+        if (P.cfg.has_tracker == 2) {
             const int per = P.cfg.tracker_saving_period;
             tc = (((E.trk_counter + 1) % per) * 4) / per;
         }

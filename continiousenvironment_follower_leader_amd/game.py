@@ -149,8 +149,12 @@ class Game:
         for name, cls in self.cfg.sensor_order:
             if cls == "LeaderPositionsTracker_v2":
                 obs[name] = v.tracker_obs(0)            # (leader_positions_hist, corridor), SEN:324-325
+            elif cls == "LeaderPositionsTracker":
+                continue                                 # the v1 tracker's own dict entry is skipped by use_sensors (CLS:269-270)
             elif cls == "FollowerInfo":
                 obs[name] = v.follower_info(name)[0].cpu().numpy().copy()   # [speed / max_speed, direction / 360] float32, SEN:834-842
+            elif cls in ("LaserSensor", "LeaderTrackDetector_vector", "LeaderTrackDetector_radar"):
+                obs[name] = v.aux_view(name)[0].cpu().numpy().copy()        # float32 arrays, SEN:131-134, 381, 476
             else:
                 a = v.laser_view(name)[0].cpu().numpy().copy()            # [max_prev_obs, lasers_count] float32, SEN:958
                 spec = next(l for l in self.cfg.lasers if l.name == name)

@@ -247,6 +247,14 @@ class VecGame:
                 return self.lasers[:, l.out_offset:l.out_offset + l.history * l.width].view(self.n, l.history, l.width)
         raise KeyError(name)
 
+    def aux_view(self, name):
+        """Output block of a LaserSensor / LeaderTrackDetector_vector / _radar sensor: float32 ``[n_envs, *shape]`` with the shape
+        the reference's ``scan`` returns (SEN:131-134, 381, 476)."""
+        for a in self.cfg.aux:
+            if a.name == name:
+                return self.lasers[:, a.out_offset:a.out_offset + a.out_len].view(self.n, *a.shape)
+        raise KeyError(name)
+
     def follower_info(self, name):
         """FollowerInfo.scan for every env (SEN:834-842): float32 [n, speed_direction_param] = (follower speed / max_speed,
         direction / 360, then ones) -- two divisions on the state, done with torch on the device."""
@@ -275,6 +283,9 @@ class VecGame:
         lo, hi = int(ei[abi.EI_CORR_LO]), int(ei[abi.EI_CORR_HI])
         cap = self.cfg.c.corr_cap
         idx = torch.arange(lo, hi, device=self.device) % cap
-        hist = self.state_field("hist")[env].view(cap, 2)[idx].cpu().numpy()
         corr = self.state_field("corr")[env].view(cap, 2, 2)[idx].cpu().numpy()
+        if self.cfg.c.has_tracker == 1:       # v1 tracker (SEN:148-229): float32 history list of its own, corridor never trimmed
+            hist = self.state_field("hist1")[env].view(-1, 2)[:int(ei[abi.EI_HIST1_LEN])].cpu().numpy()
+        else:
+            hist = self.state_field("hist")[env].view(cap, 2)[idx].cpu().numpy()
         return hist, corr

@@ -29,9 +29,10 @@
 extern "C" {
 #endif
 
-#define FTL_ABI_VERSION 1
+#define FTL_ABI_VERSION 2
 #define FTL_MAX_BEARS 4   /* bears with index >= 4 draw from `random` inside step (ENV:750-754): unsupported */
 #define FTL_MAX_LASERS 4
+#define FTL_MAX_AUX 8     /* lidar / leader-track detectors per env (ftl_aux_cfg) */
 #define FTL_MAX_REGIME 16 /* entries of leader_speed_regime / leader_acceleration_regime */
 #define FTL_OBS_NUM 10    /* numerical_features, ENV:1793-1802 */
 #define FTL_TRAJ_BLOCK 32 /* trajectory points per bounding-box block (state field "traj_bb"; traj_cap is a multiple) */
@@ -53,6 +54,7 @@ enum { FTL_LEADER_MOVING = 0, FTL_LEADER_CRASH = 1, FTL_LEADER_FINISHED = 2 };
 #define FTL_ERR_CORR_OVERFLOW 2u      /* tracker history longer than corr_cap */
 #define FTL_ERR_EMPTY_CORRIDOR 4u     /* SEN:893/962: scan with len(corridor) <= 1 (reference: UnboundLocalError) */
 #define FTL_ERR_TRACKER_SEED 8u       /* SEN:264-297: fewer than 2 seed points / popleft on empty corridor */
+#define FTL_ERR_HIST1_OVERFLOW 16u    /* v1 tracker history longer than hist1_cap */
 
 /* robot kinematic limits, px/frame and deg/frame (ENV:330-357, 556-566, 704-714; CLS:59-105) */
 typedef struct ftl_robot_params {
@@ -81,9 +83,34 @@ typedef struct ftl_laser_cfg {
     double length;            /* laser_length, px */
     double angle_offset;      /* first_laser_angle_offset, deg */
     int32_t explicit_angles;  /* 1: LeaderCorridor_lasers (SEN:571-702) -- ray i points at direction + ray_angles[i] instead of a full circle */
-    int32_t _pad2;
+    int32_t compas;           /* 1: LeaderCorridor_lasers_compas (SEN:1138-1288) -- corridor walls only, kept in float64; rows are 5*count wide:
+                                 [no wall hit | front | back | left | right] by the orientation of the nearest wall (ftl_aux_kernel) */
     double ray_angles[8];     /* deg: -40, 0, 40 [, -90, 90] [, -150, 150] (SEN:609-632) */
 } ftl_laser_cfg;
+
+/* The sensors of the registry (SEN:1291-1307) that are not ray casts against segments: their float32 outputs are further
+ * blocks of ftl_outputs.lasers, after the ray sensors' blocks, in dict order. */
+enum { FTL_AUX_LIDAR = 1,         /* LaserSensor (SEN:18-145): point-in-rect marching along available_angle / angle_step rays */
+       FTL_AUX_TRACK_VECTOR = 2,  /* LeaderTrackDetector_vector (SEN:342-387): vectors follower -> the newest / oldest tracked leader positions */
+       FTL_AUX_TRACK_RADAR = 3 }; /* LeaderTrackDetector_radar (SEN:390-487): nearest tracked position per sector of the front half plane */
+typedef struct ftl_aux_cfg {
+    int32_t kind;
+    int32_t after_tracker;        /* 1: scanned after the v2 tracker's 2nd scan of the step (dict order, CLS:269-286) */
+    int32_t out_offset, out_len;  /* filled by the library: block inside ftl_outputs.lasers, f32 elements */
+    /* lidar */
+    int32_t n_angles;             /* 1 + 2 * (number of angle_step increments until border_angle is reached), SEN:88-101 */
+    int32_t points_number;
+    int32_t return_all_points;    /* out = [n_angles * points_number][2] marching points instead of [n_angles][2] */
+    int32_t return_only_distances; /* out = [n][1] norms instead of [n][2] offsets (SEN:131-134) */
+    double  range_px;             /* sensor_range * PIXELS_TO_METER */
+    double  in_range_px;          /* range_px + 3 * PIXELS_TO_METER: objects farther than this (distance_to_rect) are ignored, SEN:78-79 */
+    double  angle_step;
+    int32_t border_angle;         /* int(available_angle / 2) */
+    /* detectors */
+    int32_t seq_len;              /* position_sequence_length */
+    int32_t detectable;           /* 0 "new", 1 "old", 2 "near" (radar only) */
+    int32_t radar_sectors;
+} ftl_aux_cfg;
 
 /* Game(**kwargs) after unit conversion (ENV:45-105, 283-357) */
 typedef struct ftl_config {
@@ -99,7 +126,8 @@ typedef struct ftl_config {
     int32_t ignore_follower_collisions;
     int32_t aggregate_reward;
     int32_t has_low_reward, has_max_distance_coef; /* early_stopping keys, ENV:1088-1107 */
-    int32_t has_tracker;                 /* LeaderPositionsTracker_v2 present */
+    int32_t has_tracker;                 /* 2: LeaderPositionsTracker_v2 present; 1: the deprecated LeaderPositionsTracker (SEN:148-229: scanned once
+                                            per step, corridor half-width max_dev, never trimmed, history thinned by eat_close_points); 0: none */
     int32_t tracker_saving_period;
     int32_t tracker_start_behind;        /* start_corridor_behind_follower */
     int32_t n_lasers;
@@ -107,7 +135,8 @@ typedef struct ftl_config {
     int32_t corr_cap;                    /* capacity of tracker history / corridor ring per env */
     int32_t route_cap;                   /* capacity of the planned route per scenario (waypoints) */
     int32_t init_traj_cap;               /* capacity of the initial trajectory per scenario */
-    int32_t _pad0[2];
+    int32_t hist1_cap;                   /* capacity of the v1 tracker's position history per env (points) */
+    int32_t trk1_eat_close_points;       /* v1 tracker: eat_close_points */
     double low_reward, max_distance_coef;
     double min_distance, max_distance, max_dev; /* px */
     double leader_pos_epsilon;
@@ -130,6 +159,9 @@ typedef struct ftl_config {
     double speed_lo[FTL_MAX_REGIME], speed_hi[FTL_MAX_REGIME];
     double acc_val[FTL_MAX_REGIME];
     uint64_t rng_seed;                   /* seed of the counter-based streams that replace the global `random` (ftl_uniform01) */
+    double trk1_eat_radius;              /* v1 tracker: max(follower.width, follower.height) in px (SEN:213) */
+    int32_t n_aux, _pad2;
+    ftl_aux_cfg aux[FTL_MAX_AUX];
 } ftl_config;
 
 /* Counter-based uniform stream that stands in for `random.uniform` at ENV:1156: the draw of
@@ -209,8 +241,9 @@ size_t ftl_sizeof_scen_params(void);
 /* step()/reset() outputs = (obs, reward, done, info) of ENV:945 for n envs, device arrays */
 typedef struct ftl_outputs {
     float*   obs_num;    /* [n][10]            numerical_features (ENV:1793-1802) */
-    float*   lasers;     /* [n][lasers_len]    per sensor k a [history_k][width_k] block at lasers[k].out_offset,
-                            width_k = count_k (4*count_k with pad_sectors) */
+    float*   lasers;     /* [n][lasers_len]    per ray sensor k a [history_k][width_k] block at lasers[k].out_offset, width_k = count_k
+                            (4*count_k with pad_sectors, 5*count_k for compas); then per aux sensor a block of aux[j].out_len at
+                            aux[j].out_offset */
     double*  target;     /* [n][2]             leader_target_point (ENV:1803-1806) */
     double*  reward;     /* [n]                last-frame reward (ENV:935-936, 1136-1141) */
     uint8_t* done;       /* [n] */
@@ -305,6 +338,9 @@ enum {
     FTL_EI_HINT_X, FTL_EI_HINT_Y, FTL_EI_CLR_GREEN, FTL_EI_CLR_ALL,
     FTL_EI_FPS,        /* frames of the NEXT step of this env under random_frames_per_step (drawn at the end of a step, ENV:939-940;
                           kept across resets like the reference's attribute; 0 = not drawn yet) */
+    FTL_EI_HW0_LO, FTL_EI_HW0_HI, /* tracker history window after the FIRST tracker scan of the step (what a detector that precedes the tracker
+                          in dict order sees); after the second one it is FTL_EI_CORR_LO / FTL_EI_CORR_HI */
+    FTL_EI_HIST1_LEN,   /* v1 tracker: points in the "hist1" field */
     FTL_EI_ERROR_STICKY, /* OR of every FTL_ERR_* bit this env slot ever raised: survives reset / auto-reset (FTL_EI_ERROR is per
                           episode); cleared by ftl_episode_metrics(FTL_METRICS_CLEAR) */
     FTL_EI_COUNT

@@ -82,7 +82,7 @@ typedef struct ftlo_env {
 
 /* ------------------------------------------------------------------ helpers */
 
-static int laser_width(const ftl_laser_cfg* L) { return L->pad_sectors ? 4 * L->count : L->count; } /* SEN:932-958 */
+static int laser_width(const ftl_laser_cfg* L) { return L->compas ? 5 * L->count : (L->pad_sectors ? 4 * L->count : L->count); } /* SEN:932-958, 1226 */
 
 /* scipy.spatial.distance.euclidean on two float32 points */
 static double euclid_f32(float ax, float ay, float bx, float by) {
@@ -663,13 +663,229 @@ static void laser_scan(ftlo_env* e, int k, float* out) {
     }
 }
 
+
+/* ------------------------------------------------------------------ LeaderPositionsTracker v1 (SEN:148-229) */
+/* hist = list of float32 points (stored in e->hist as doubles with hist_f64 = 0); corridor pairs are appended and never
+ * popped; eat_close_points deletes history points within max(width, height) of the follower after every scan. */
+static void tracker1_scan(ftlo_env* e) {
+    const ftl_config* c = &e->cfg;
+    const robot_t* leader = &e->rb[0]; const robot_t* f = &e->rb[1];
+    if (e->trk_counter % c->tracker_saving_period == 0) {
+        if (e->hist_len > 0 && e->hist[2 * (e->hist_len - 1)] == (double)leader->px && e->hist[2 * (e->hist_len - 1) + 1] == (double)leader->py)
+            return;                                                       /* SEN:178-183: nothing at all happens */
+        if (e->hist_len == 0) hist_push(e, (double)f->px, (double)f->py, 0);   /* SEN:185-186 */
+        hist_push(e, (double)leader->px, (double)leader->py, 0);           /* SEN:187 */
+        if (e->hist_len > 1) {                                            /* SEN:188-195 */
+            const double* p1 = e->hist + 2 * (e->hist_len - 1); const double* p0 = e->hist + 2 * (e->hist_len - 2);
+            float fx = (float)p1[0] - (float)p0[0], fy = (float)p1[1] - (float)p0[1];
+            float nrm = sqrtf(fx * fx + fy * fy);
+            float sc = (float)c->corridor_width / nrm;                    /* env.max_dev (python float) / np.float32 -> float32 */
+            fx *= sc; fy *= sc;
+            double vx = (double)fx, vy = (double)fy;
+            double c90 = cos(90.0 * DEG2RAD), s90 = sin(90.0 * DEG2RAD), cm90 = cos(-90.0 * DEG2RAD), sm90 = sin(-90.0 * DEG2RAD);
+            double r[2] = { (c90 * vx + (-s90) * vy) + p0[0], (s90 * vx + c90 * vy) + p0[1] };
+            double l[2] = { (cm90 * vx + (-sm90) * vy) + p0[0], (sm90 * vx + cm90 * vy) + p0[1] };
+            corr_push(e, r, l);
+        }
+    }
+    e->trk_counter += 1;
+    if (c->trk1_eat_close_points && e->hist_len > 0) {                    /* SEN:211-216 */
+        int w = 0;
+        const float thr = (float)c->trk1_eat_radius;                      /* float32 norms <= python float: compared in float32 */
+        for (int i = 0; i < e->hist_len; i++) {
+            float dx = (float)e->hist[2 * i] - f->px, dy = (float)e->hist[2 * i + 1] - f->py;
+            float nrm = sqrtf(dx * dx + dy * dy);
+            if (nrm <= thr) continue;
+            e->hist[2 * w] = e->hist[2 * i]; e->hist[2 * w + 1] = e->hist[2 * i + 1]; e->hist_f64[w] = 0; w++;
+        }
+        e->hist_len = w;
+    }
+}
+
+/* ------------------------------------------------------------------ LeaderCorridor_lasers_compas (SEN:1138-1288) */
+/* Corridor walls only, kept in float64 (no float32 cast as at SEN:672); wall list order = front, back, left walls, right walls
+ * (SEN:1166); the nearest hit's wall orientation selects one of four N-wide blocks after the "no wall" block. */
+typedef struct { double a[2], b[2]; int cls; } wall_t;    /* cls: 0 front, 1 back, 2 left, 3 right */
+typedef struct { wall_t* w; int n; int valid; } wsnap_t;
+
+static int wall_hit(const wall_t* s, float cxf, float cyf, double dx, double dy) {   /* SEN:608-614, every operand float64 */
+    double ax = s->a[0], ay = s->a[1], bx = s->b[0], by = s->b[1], cx = (double)cxf, cy = (double)cyf;
+    int t1 = (dy - ay) * (cx - ax) > (cy - ay) * (dx - ax);   /* ccw(A,C,D) */
+    int t2 = (dy - by) * (cx - bx) > (cy - by) * (dx - bx);   /* ccw(B,C,D) */
+    int t3 = (cy - ay) * (bx - ax) > (by - ay) * (cx - ax);   /* ccw(A,B,C) */
+    int t4 = (dy - ay) * (bx - ax) > (by - ay) * (dx - ax);   /* ccw(A,B,D) */
+    return (t1 != t2) && (t3 != t4);
+}
+static double wall_hit_point(const wall_t* s, float cxf, float cyf, double ex, double ey, double* ox, double* oy) {   /* SEN:626-640 */
+    double cx = (double)cxf, cy = (double)cyf;
+    double dax = s->b[0] - s->a[0], day = s->b[1] - s->a[1];
+    double dbx = ex - cx, dby = ey - cy;
+    double dpx = s->a[0] - cx, dpy = s->a[1] - cy;
+    double dapx = -day, dapy = dax;
+    double denom = dapx * dbx + dapy * dby;
+    double num = dapx * dpx + dapy * dpy;
+    double t = num / denom;
+    double x = t * dbx + cx, y = t * dby + cy;
+    *ox = x; *oy = y;
+    double qx = x - cx, qy = y - cy;
+    return sqrt(qx * qx + qy * qy);                       /* np.linalg.norm(x - position, axis=1) */
+}
+static void compas_scan(ftlo_env* e, int k, float* out) {
+    const ftl_laser_cfg* L = &e->cfg.lasers[k];
+    const robot_t* f = &e->rb[1];
+    const int N = L->count, H = L->history, W = 5 * N;
+    const double period = 360.0 / N;
+    if (e->corr_len <= 1) {          /* SEN:1192/1244: all_obs_arr is unbound -> UnboundLocalError */
+        e->error |= FTL_ERR_EMPTY_CORRIDOR;
+        for (int i = 0; i < H * W; i++) out[i] = (i % W) < N ? (float)L->length : 0.0f;
+        return;
+    }
+    wsnap_t* hs = (wsnap_t*)e->snaps[k];
+    free(hs[0].w);
+    memmove(hs, hs + 1, sizeof(wsnap_t) * (size_t)(H - 1));
+    {   /* collect_obstacle_edges, SEN:1153-1176 */
+        const int C = e->corr_len;
+        wall_t* w = (wall_t*)malloc(sizeof(wall_t) * (size_t)(2 * C + 2));
+        int n = 0;
+        const double* first = e->corr; const double* last = e->corr + 4 * (C - 1);
+        w[n].a[0] = last[0]; w[n].a[1] = last[1]; w[n].b[0] = last[2]; w[n].b[1] = last[3]; w[n].cls = 0; n++;      /* front: corridor[-1] */
+        w[n].a[0] = first[0]; w[n].a[1] = first[1]; w[n].b[0] = first[2]; w[n].b[1] = first[3]; w[n].cls = 1; n++;  /* back: corridor[0] */
+        for (int i = 0; i < C - 1; i++) { const double* p = e->corr + 4 * i; const double* q = p + 4;
+            w[n].a[0] = p[2]; w[n].a[1] = p[3]; w[n].b[0] = q[2]; w[n].b[1] = q[3]; w[n].cls = 2; n++; }             /* left walls */
+        for (int i = 0; i < C - 1; i++) { const double* p = e->corr + 4 * i; const double* q = p + 4;
+            w[n].a[0] = p[0]; w[n].a[1] = p[1]; w[n].b[0] = q[0]; w[n].b[1] = q[1]; w[n].cls = 3; n++; }             /* right walls */
+        hs[H - 1].w = w; hs[H - 1].n = n; hs[H - 1].valid = 1;
+    }
+    for (int i = 0; i < H * W; i++) out[i] = 0.0f;
+    for (int i = 0; i < N; i++) {
+        double th = ((f->direction + L->angle_offset) + i * period) * DEG2RAD;
+        double ex = (double)f->px + cos(th) * L->length, ey = (double)f->py + sin(th) * L->length;
+        for (int j = 0; j < H; j++) {
+            double bx = ex, by = ey; int found = 0, cls = -1; double best = 0;
+            if (hs[j].valid)
+                for (int m = 0; m < hs[j].n; m++)
+                    if (wall_hit(&hs[j].w[m], f->px, f->py, ex, ey)) {
+                        double x, y, d = wall_hit_point(&hs[j].w[m], f->px, f->py, ex, ey, &x, &y);
+                        if (!found || d < best) { best = d; bx = x; by = y; cls = hs[j].w[m].cls; found = 1; }   /* argmin: first minimum */
+                    }
+            double qx = bx - (double)f->px, qy = by - (double)f->py;
+            float val = (float)sqrt(fma(qy, qy, qx * qx));                         /* np.linalg.norm 1-D, SEN:1229-1243 */
+            out[j * W + (found ? (1 + cls) * N : 0) + i] = val;                    /* the "no wall" slot stays 0 on a hit */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ LaserSensor (SEN:18-145) */
+static void lidar_scan(const ftlo_env* e, const ftl_aux_cfg* A, float* out) {
+    const robot_t* f = &e->rb[1];
+    /* objects_in_range, SEN:72-79: every object but the follower whose distance_to_rect (MISC:29-44: nearest of the 4 corners and
+     * 4 edge mid-points, scipy euclidean on a float32 point and an int tuple = float64 dnrm2) is within range + 3 PIXELS_TO_METER */
+    int nobj = 1 + e->cfg.n_static + e->cfg.n_bears, nin = 0;
+    int (*rc)[4] = (int (*)[4])malloc(sizeof(int[4]) * (size_t)nobj);
+    for (int o = 0; o < nobj; o++) {
+        int x, y, w, h;
+        if (o == 0) { x = e->rb[0].rx; y = e->rb[0].ry; w = e->rb[0].rw; h = e->rb[0].rh; }
+        else if (o <= e->cfg.n_static) { const int32_t* q = e->srect + 4 * (o - 1); x = q[0]; y = q[1]; w = q[2]; h = q[3]; }
+        else { const robot_t* b = &e->rb[2 + (o - 1 - e->cfg.n_static)]; x = b->rx; y = b->ry; w = b->rw; h = b->rh; }
+        const int px[8] = { x, x, x + w, x + w, x + (w >> 1), x, x + (w >> 1), x + w };
+        const int py[8] = { y, y + h, y, y + h, y, y + (h >> 1), y + h, y + (h >> 1) };
+        double dmin = INFINITY;
+        for (int k = 0; k < 8; k++) { double d = euclid_f64((double)f->px, (double)f->py, (double)px[k], (double)py[k]); if (d < dmin) dmin = d; }
+        if (dmin <= A->in_range_px) { rc[nin][0] = x; rc[nin][1] = y; rc[nin][2] = w; rc[nin][3] = h; nin++; }
+    }
+    const float x1 = f->px, y1 = f->py;
+    for (int a = 0; a < A->n_angles; a++) {
+        /* SEN:88-101: -direction, then +- k * angle_step (angle_correction on those) */
+        double angle = -f->direction;
+        if (a > 0) { double k = (double)((a + 1) / 2) * A->angle_step; angle = angle_correction(a & 1 ? -f->direction + k : -f->direction - k); }
+        const double rad = angle * DEG2RAD;
+        /* np.float32 + python float -> float32 (NEP 50): the float64 offset is rounded to float32 first */
+        const float x2 = x1 + (float)(A->range_px * cos(rad)), y2 = y1 - (float)(A->range_px * sin(rad));
+        float ptx = x2, pty = y2;
+        for (int i = 0; i < A->points_number; i++) {
+            const double u = (double)i / (double)A->points_number;
+            const float cx = x2 * (float)u + x1 * (float)(1.0 - u), cy = y2 * (float)u + y1 * (float)(1.0 - u);
+            int hit = 0;
+            for (int o = 0; o < nin && !hit; o++)         /* Rect.collidepoint: x <= px < x + w and y <= py < y + h */
+                hit = (float)rc[o][0] <= cx && cx < (float)(rc[o][0] + rc[o][2]) && (float)rc[o][1] <= cy && cy < (float)(rc[o][1] + rc[o][3]);
+            if (hit) { ptx = cx; pty = cy; break; }
+        }
+        const float dx = ptx - x1, dy = pty - y1;         /* sensed_points - position, float32 */
+        if (A->return_only_distances) out[a] = sqrtf(dx * dx + dy * dy);
+        else { out[2 * a] = dx; out[2 * a + 1] = dy; }
+    }
+    free(rc);
+}
+
+/* ------------------------------------------------------------------ LeaderTrackDetector_vector / _radar (SEN:342-487) */
+/* the slice of the tracked positions a detector looks at: "new" = the last seq_len points, "old" = the first, "near" = all */
+static void track_slice(const ftlo_env* e, const ftl_aux_cfg* A, int* lo, int* hi) {
+    int n = e->hist_len;
+    if (A->detectable == 0) { *lo = n - A->seq_len > 0 ? n - A->seq_len : 0; *hi = n; }
+    else if (A->detectable == 1) { *lo = 0; *hi = n < A->seq_len ? n : A->seq_len; }
+    else { *lo = 0; *hi = n; }
+}
+static void track_vector_scan(const ftlo_env* e, const ftl_aux_cfg* A, float* out) {
+    const robot_t* f = &e->rb[1];
+    for (int i = 0; i < 2 * A->seq_len; i++) out[i] = 0.0f;
+    int lo, hi; track_slice(e, A, &lo, &hi);
+    /* np.array(slice) - position: float32 - float32 when every point of the slice is float32, else float64; either way the
+     * float32 store equals the correctly rounded difference of the two values */
+    for (int i = lo; i < hi; i++) {
+        out[2 * (i - lo)] = (float)(e->hist[2 * i] - (double)f->px);
+        out[2 * (i - lo) + 1] = (float)(e->hist[2 * i + 1] - (double)f->py);
+    }
+}
+static void track_radar_scan(const ftlo_env* e, const ftl_aux_cfg* A, float* out) {
+    const robot_t* f = &e->rb[1];
+    const int S = A->radar_sectors;
+    for (int i = 0; i < S; i++) out[i] = 0.0f;
+    if (e->hist_len == 0) return;
+    int lo, hi; track_slice(e, A, &lo, &hi);
+    /* followerDirVec / followerRightVec = rotateVector([1, 0], angle): (cos, sin) of the angle, SEN:424-428 */
+    const double dth = f->direction * DEG2RAD;
+    double rdir = f->direction + 90; if (rdir >= 360) rdir -= 360;
+    const double rth = rdir * DEG2RAD;
+    const double dvx = cos(dth) * 1 + (-sin(dth)) * 0, dvy = sin(dth) * 1 + cos(dth) * 0;
+    const double rvx = cos(rth) * 1 + (-sin(rth)) * 0, rvy = sin(rth) * 1 + cos(rth) * 0;
+    const double nd = sqrt(fma(dvy, dvy, dvx * dvx)), nr = sqrt(fma(rvy, rvy, rvx * rvx));     /* np.linalg.norm 1-D float64 */
+    int any64 = 0;
+    for (int i = lo; i < hi; i++) any64 |= e->hist_f64[i];
+    const double sa = PI_D / S;
+    double* best = (double*)malloc(sizeof(double) * (size_t)S);
+    for (int s = 0; s < S; s++) best[s] = INFINITY;
+    for (int i = lo; i < hi; i++) {
+        double vx, vy, dist;
+        if (any64) { vx = e->hist[2 * i] - (double)f->px; vy = e->hist[2 * i + 1] - (double)f->py; dist = sqrt(vx * vx + vy * vy); }
+        else { float fx = (float)e->hist[2 * i] - f->px, fy = (float)e->hist[2 * i + 1] - f->py; vx = fx; vy = fy; dist = (double)sqrtf(fx * fx + fy * fy); }
+        const double ad = acos((vx * dvx + vy * dvy) / (dist * nd));       /* calculateAngle, MISC:56-63 */
+        double ar = acos((vx * rvx + vy * rvy) / (dist * nr));
+        if (ad > PI_D / 2) ar = -ar;
+        for (int s = 0; s < S; s++)
+            if (ar >= sa * s && ar < sa * (s + 1) && dist < best[s]) best[s] = dist;     /* np.min over the sector */
+    }
+    for (int s = 0; s < S; s++) if (best[s] != INFINITY) out[s] = (float)best[s];
+    free(best);
+}
+
 /* CLS:255-288 */
 static void use_sensors(ftlo_env* e, float* lasers_out) {
     const ftl_config* c = &e->cfg;
-    if (c->has_tracker) tracker_scan(e);                               /* CLS:263-267 */
-    for (int k = 0; k < c->n_lasers; k++) if (!c->lasers[k].after_tracker) laser_scan(e, k, lasers_out + c->lasers[k].out_offset);
-    if (c->has_tracker) tracker_scan(e);                               /* CLS:285-286 */
-    for (int k = 0; k < c->n_lasers; k++) if (c->lasers[k].after_tracker) laser_scan(e, k, lasers_out + c->lasers[k].out_offset);
+    if (c->has_tracker == 1) tracker1_scan(e);                         /* CLS:257-261: the v1 tracker, once per step */
+    if (c->has_tracker == 2) tracker_scan(e);                          /* CLS:263-267 */
+    for (int g = 0; g < 2; g++) {
+        if (g == 1 && c->has_tracker == 2) tracker_scan(e);            /* CLS:285-286: the v2 tracker again, at its dict position */
+        for (int k = 0; k < c->n_lasers; k++) if (c->lasers[k].after_tracker == g) {
+            if (c->lasers[k].compas) compas_scan(e, k, lasers_out + c->lasers[k].out_offset);
+            else laser_scan(e, k, lasers_out + c->lasers[k].out_offset);
+        }
+        for (int j = 0; j < c->n_aux; j++) if (c->aux[j].after_tracker == g) {
+            float* out = lasers_out + c->aux[j].out_offset;
+            if (c->aux[j].kind == FTL_AUX_LIDAR) lidar_scan(e, &c->aux[j], out);
+            else if (c->aux[j].kind == FTL_AUX_TRACK_VECTOR) track_vector_scan(e, &c->aux[j], out);
+            else if (c->aux[j].kind == FTL_AUX_TRACK_RADAR) track_radar_scan(e, &c->aux[j], out);
+        }
+    }
 }
 
 /* ENV:1789-1810 */
@@ -691,6 +907,11 @@ ftlo_env* ftlo_create(const ftl_config* cfg) {
     e->cfg = *cfg;
     int off = 0;
     for (int k = 0; k < cfg->n_lasers; k++) { e->cfg.lasers[k].out_offset = off; off += cfg->lasers[k].history * laser_width(&cfg->lasers[k]); }
+    for (int j = 0; j < cfg->n_aux; j++) {       /* lidar / detector blocks follow the ray sensors' blocks */
+        ftl_aux_cfg* a = &e->cfg.aux[j];
+        a->out_len = a->kind == FTL_AUX_LIDAR ? a->n_angles * (a->return_only_distances ? 1 : 2) : a->kind == FTL_AUX_TRACK_VECTOR ? 2 * a->seq_len : a->radar_sectors;
+        a->out_offset = off; off += a->out_len;
+    }
     e->lasers_len = off;
     e->R = 2 + cfg->n_bears;
     e->srect = (int32_t*)calloc((size_t)(cfg->n_static > 0 ? cfg->n_static : 1) * 4, sizeof(int32_t));
@@ -701,7 +922,7 @@ ftlo_env* ftlo_create(const ftl_config* cfg) {
     e->hist = (double*)calloc((size_t)cfg->corr_cap * 2, sizeof(double));
     e->hist_f64 = (uint8_t*)calloc((size_t)cfg->corr_cap, 1);
     e->corr = (double*)calloc((size_t)cfg->corr_cap * 4, sizeof(double));
-    for (int k = 0; k < cfg->n_lasers; k++) e->snaps[k] = (snapshot_t*)calloc((size_t)cfg->lasers[k].history, sizeof(snapshot_t));
+    for (int k = 0; k < cfg->n_lasers; k++) e->snaps[k] = (snapshot_t*)calloc((size_t)cfg->lasers[k].history, sizeof(snapshot_t) > sizeof(wsnap_t) ? sizeof(snapshot_t) : sizeof(wsnap_t));
     e->rb[0].p = &e->cfg.leader; e->rb[1].p = &e->cfg.follower;
     for (int b = 0; b < FTL_MAX_BEARS; b++) e->rb[2 + b].p = &e->cfg.bear;
     return e;

@@ -85,6 +85,8 @@ class OracleEnv:
         out = {"num": self.obs_num.copy(), "target": self.target.copy()}
         for l in self.cfg.lasers:
             out[l.name] = self.lasers[l.out_offset:l.out_offset + l.history * l.width].reshape(l.history, l.width).copy()
+        for a in self.cfg.aux:
+            out[a.name] = self.lasers[a.out_offset:a.out_offset + a.out_len].reshape(a.shape).copy()
         return out
 
     def step(self, action):

@@ -135,6 +135,40 @@ CONFIGS = {
                                    "back_lasers_count": 2, "laser_length": 90})])), post=None),
     # three bears (odd index -> _move_bear_v4), sensors of B
     "B3": dict(kwargs=dict(bear_number=3, follower_sensors=SENSORS_B), post=None),
+    # config C: B's tracker + Prev sensor + two LeaderCorridor_lasers_compas (SEN:1138-1288), one scanned before the tracker's second
+    # scan of the step and one after it
+    "C": dict(kwargs=dict(bear_number=1, follower_sensors=OrderedDict([
+        ("compas_first", {"sensor_class": "LeaderCorridor_lasers_compas", "react_to_green_zone": True, "react_to_safe_corridor": True,
+                          "react_to_obstacles": False, "lasers_count": 12, "laser_length": 90, "max_prev_obs": 5, "pad_sectors": False}),
+        ("LeaderPositionsTracker_v2", dict(SENSORS_B["LeaderPositionsTracker_v2"])),
+        ("LeaderCorridor_lasers_all", dict(SENSORS_B["LeaderCorridor_lasers_all"])),
+        ("LeaderCorridor_lasers_compas", {"sensor_class": "LeaderCorridor_lasers_compas", "react_to_green_zone": True,
+                                          "react_to_safe_corridor": True, "react_to_obstacles": False, "lasers_count": 20,
+                                          "laser_length": 120, "max_prev_obs": 5, "pad_sectors": False,
+                                          "first_laser_angle_offset": 0})])), post=None),
+    # config L: lidar (SEN:18-145, offsets and distances-only) + the leader-track detectors (SEN:342-487) on the v2 tracker's history,
+    # one detector registered BEFORE the tracker (it sees the history after the first scan of the step only)
+    "L": dict(kwargs=dict(bear_number=2, follower_sensors=OrderedDict([
+        ("track_old_first", {"sensor_class": "LeaderTrackDetector_vector", "position_sequence_length": 8, "detectable_positions": "old"}),
+        ("LeaderPositionsTracker_v2", dict(SENSORS_B["LeaderPositionsTracker_v2"])),
+        ("LaserSensor", {"sensor_class": "LaserSensor"}),
+        ("lidar_front", {"sensor_class": "LaserSensor", "available_angle": 180, "angle_step": 15, "points_number": 10, "sensor_range": 3,
+                         "return_only_distances": True}),
+        ("track_new", {"sensor_class": "LeaderTrackDetector_vector", "position_sequence_length": 20, "detectable_positions": "new"}),
+        ("radar_near", {"sensor_class": "LeaderTrackDetector_radar", "detectable_positions": "near", "radar_sectors_number": 36}),
+        ("radar_old", {"sensor_class": "LeaderTrackDetector_radar", "position_sequence_length": 12, "radar_sectors_number": 18}),
+        ("LeaderCorridor_lasers_all", dict(SENSORS_B["LeaderCorridor_lasers_all"]))])), post=None),
+    # config T: the deprecated v1 tracker (SEN:148-229; scanned once per step, corridor half-width max_dev, eat_close_points) feeding a
+    # lasers_v2 sensor, a LeaderCorridor_lasers one and both detectors (a Prev_lasers_v2 sensor raises at reset on this tracker: its
+    # corridor holds one pair after the first scan, SEN:893/962)
+    "T": dict(kwargs=dict(bear_number=1, follower_sensors=OrderedDict([
+        ("LeaderPositionsTracker", {"sensor_class": "LeaderPositionsTracker", "saving_period": 4}),
+        ("LeaderCorridor_lasers", {"sensor_class": "LeaderCorridor_lasers", "react_to_obstacles": "dynamic", "front_lasers_count": 3}),
+        ("lasers_now", {"sensor_class": "LeaderCorridor_lasers_v2", "react_to_obstacles": True, "react_to_green_zone": True,
+                        "react_to_safe_corridor": True, "lasers_count": 24, "laser_length": 130}),
+        ("track_new", {"sensor_class": "LeaderTrackDetector_vector", "position_sequence_length": 16, "detectable_positions": "new"}),
+        ("radar_new", {"sensor_class": "LeaderTrackDetector_radar", "position_sequence_length": 30, "detectable_positions": "new",
+                       "radar_sectors_number": 20})])), post=None),
     # config M ("mixed"): a Prev_lasers_v2 sensor next to a LeaderCorridor_lasers_v2 one and FollowerInfo, every entry with a
     # "sensor_class" key so that ContinuousObserveModifier_sensorPrev constructs on it -- the wrapper must pick the Prev sensor
     # only (wrappers.py:204, 214)
@@ -269,6 +303,10 @@ def obs_record(g, obs, laser_names):
     for n, v in g.follower_sensors.items():
         if v.get("sensor_class", n) == "FollowerInfo":
             rec["finfo:" + n] = np.asarray(obs[n], dtype=np.float32)
+        if v.get("sensor_class", n) in ("LaserSensor", "LeaderTrackDetector_vector", "LeaderTrackDetector_radar"):
+            a = np.asarray(obs[n])
+            assert a.dtype == np.float32, (n, a.dtype)
+            rec["aux:" + n] = a.copy()
     return rec
 
 
@@ -285,6 +323,8 @@ def debug_record(g):
                                dtype=np.int64),
              acc=np.array([float(g.accumulated_penalty), float(g.overall_reward)]))
     tr = g.follower.sensors.get("LeaderPositionsTracker_v2") if hasattr(g.follower, "sensors") else None
+    if tr is None and hasattr(g.follower, "sensors") and type(g.follower.sensors.get("LeaderPositionsTracker")).__name__ == "LeaderPositionsTracker":
+        tr = g.follower.sensors["LeaderPositionsTracker"]      # the v1 class under its own key (config T)
     if tr is not None:
         hist = np.array([[float(p[0]), float(p[1])] for p in tr.leader_positions_hist], dtype=np.float64).reshape(-1, 2)
         corr = np.array([[float(c[0][0]), float(c[0][1]), float(c[1][0]), float(c[1][1])] for c in tr.corridor],
@@ -346,7 +386,8 @@ def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_do
     g = r.game
     wrap = sensor_prev_wrapper(g)
     laser_names = [k for k, v in g.follower_sensors.items()
-                   if v.get("sensor_class", k) in ("LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2", "LeaderCorridor_lasers")]
+                   if v.get("sensor_class", k) in ("LeaderCorridor_Prev_lasers_v2", "LeaderCorridor_lasers_v2", "LeaderCorridor_lasers",
+                                                   "LeaderCorridor_lasers_compas")]
     scen = scenario_of(g)
     out = {"scen:" + k: v for k, v in scen.items()}
     for k, v in obs_record(g, obs0, laser_names).items():
@@ -429,6 +470,12 @@ EPISODES = [
     ("D_s2_chase", "D", 2, "chase", 60),
     ("D_s7_random", "D", 7, "random", 60),
     ("M_s3_chase", "M", 3, "chase", 100),
+    ("C_s1_chase", "C", 1, "chase", 150),
+    ("C_s5_random", "C", 5, "random", 100),
+    ("L_s2_chase", "L", 2, "chase", 150),
+    ("L_s7_random", "L", 7, "random", 100),
+    ("T_s3_chase", "T", 3, "chase", 200),
+    ("T_s9_random", "T", 9, "random", 100),
     ("Bshort_s4_chase", "B_short", 4, "chase", 60),
     ("Bshort_s9_random", "B_short", 9, "random", 60),
     ("Bnobear_s1_chase", "B_nobear", 1, "chase", 520),

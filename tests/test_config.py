@@ -57,7 +57,10 @@ def test_sensor_registry_and_dict_order():
     (dict(multiple_end_points=True, path_finding_algorythm="astar"), NotImplementedError),   # ENV:239-243
     (dict(follower_sensors={"x": {"sensor_class": "LeaderCorridor_Prev_lasers_v2", "lasers_count": 13, "max_prev_obs": 5}}), ValueError),  # SEN:761-762
     (dict(follower_sensors={"mystery": {}}), ValueError),                            # CLS:249
-    (dict(follower_sensors={"LaserSensor": {}}), NotImplementedError),               # outside the accelerated path
+    (dict(follower_sensors={"LaserSensor": {"return_all_points": True}}), NotImplementedError),   # ragged output (SEN:112-113)
+    (dict(follower_sensors={"LeaderTrackDetector_radar": {}}), ValueError),          # CLS:240-243: no tracker registered
+    (dict(follower_sensors={"c": {"sensor_class": "LeaderCorridor_lasers_compas", "max_prev_obs": 5}}), ValueError),   # SEN:1148-1151: flags
+    (dict(follower_sensors={"c": {"sensor_class": "LeaderCorridor_Prev_lasers_v3", "max_prev_obs": 5}}), ValueError),  # SEN:993
     (dict(manual_control=True), NotImplementedError),
     (dict(bear_number=5), NotImplementedError),
 ])

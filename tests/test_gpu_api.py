@@ -67,7 +67,8 @@ def test_game_facade_replays_a_reference_episode():
     g.close()
 
 
-@pytest.mark.parametrize("name", ["B_s3_chase_noisy", "E_s5_random", "D_s2_chase", "F_s7_chase", "G_s2_chase"])
+@pytest.mark.parametrize("name", ["B_s3_chase_noisy", "E_s5_random", "D_s2_chase", "F_s7_chase", "G_s2_chase", "C_s1_chase", "L_s2_chase",
+                                  "T_s3_chase"])
 def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
     """The whole drop-in: Game(**kwargs); seed(s); reset(); step(a)... reproduces the reference's episode with the
     scenario built by the host-side generator from the python seed alone (nothing captured from the reference)."""
@@ -91,6 +92,14 @@ def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
         assert abs(rew - z["reward"][t]) <= 1e-5 and done == bool(z["done"][t])
         for fname, _k in g.cfg.follower_info:
             assert obs[fname].dtype == np.float32 and np.array_equal(obs[fname], z["obs:finfo:" + fname][t])
+        for a in g.cfg.aux:                    # LaserSensor / LeaderTrackDetector_vector / _radar: float32 arrays of the reference's shapes
+            ref = z["obs:aux:" + a.name][t]
+            assert obs[a.name].dtype == np.float32 and obs[a.name].shape == ref.shape and close(obs[a.name], ref).all(), (t, a.name)
+    # the obs dict has the reference's keys in dict order; the v1 tracker's own entry is skipped by use_sensors (CLS:269-270)
+    sens = kw["follower_sensors"]
+    assert list(obs.keys()) == ["numerical_features", "leader_target_point"] + [k for k, v in sens.items() if v.get("sensor_class", k) != "LeaderPositionsTracker"]
+    if name.startswith("C_"):
+        assert obs["LeaderCorridor_lasers_compas"].shape == (5, 100) and obs["compas_first"].shape == (5, 60)
     if name.startswith("G_"):      # LeaderCorridor_lasers_v2 returns one row [lasers_count], in the dict position of the sensor
         assert list(obs.keys()) == ["numerical_features", "leader_target_point"] + list(kw["follower_sensors"].keys())
         assert obs["lasers_now"].shape == (36,) and obs["lasers_now_first"].shape == (20,) and obs["LeaderCorridor_lasers"].shape == (7,)
@@ -221,12 +230,13 @@ def test_full_size_properties_65536_envs():
     big.close(); small.close()
 
 
-@pytest.mark.parametrize("name", ["B_s1_chase", "Bpad_s4_chase", "F_s7_chase", "M_s3_chase"])
+@pytest.mark.parametrize("name", ["B_s1_chase", "Bpad_s4_chase", "F_s7_chase", "M_s3_chase", "C_s1_chase"])
 def test_fused_sensor_prev_wrapper_output(name):
     """Row f1 of the scope table: the policy input tensor written by the ray kernel's epilogue, against the output of the
     reference's OWN ContinuousObserveModifier_sensorPrev.observation (utils/wrappers.py:200-221) recorded by make_golden.py
     (`wrap_sensorPrev`).  Config M mixes a LeaderCorridor_lasers_v2 sensor in: the wrapper -- and policy_obs -- take the
-    Prev_lasers_v2 sensors only (wrappers.py:204, 214); F registers ten snapshots and the tracker last."""
+    Prev_lasers_v2 sensors only (wrappers.py:204, 214); F registers ten snapshots and the tracker last; C adds two
+    LeaderCorridor_lasers_compas sensors (5 * lasers_count columns each, wrappers.py:214-219), written by ftl_aux_kernel."""
     from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
     z, meta = load_episode(name)
     cfg = config_for(meta, scen_route_len=len(z["scen:route"]))

@@ -81,6 +81,34 @@ def test_config_D_matches_oracle_batch(policy):
     env.close()
 
 
+@pytest.mark.parametrize("ep", ["C_s1_chase", "L_s2_chase", "T_s3_chase"])
+def test_f3_sensors_match_oracle_batch(ep):
+    """Row f3: LeaderCorridor_lasers_compas (config C), LaserSensor + LeaderTrackDetector_vector / _radar (L), the v1 tracker with
+    detectors and lenient ray sensors (T) on 192 envs x 50 steps with explicit resets of finished envs -- every output block."""
+    n, steps = 192, 50
+    cfg, pool = _cfg_pool(ep, 96)
+    env = _vec(n, cfg, pool)
+    scen = pool_scenarios(pool)
+    idx = np.arange(n) % pool.n
+    env.reset(torch.from_numpy(idx.astype(np.int32)))
+    ora = OracleBatch(cfg, n)
+    ora.reset(scen, idx)
+    _compare_with_oracle(env, ora, cfg, (ep, "reset"))
+    for t in range(steps):
+        a = _actions(cfg, n, t, "mixed" if t % 2 else "random", seed=13)
+        env.step(torch.tensor(a, dtype=torch.float64, device="cuda:0"))
+        ora.step(a)
+        _compare_with_oracle(env, ora, cfg, (ep, t))
+        d = ora.done.astype(bool)
+        if d.any() and t % 10 == 9:                 # masked reset of the finished envs to their next scenario on both sides
+            idx = np.where(d, (idx + n) % pool.n, idx)
+            env.reset(torch.from_numpy(idx.astype(np.int32)), mask=torch.from_numpy(d.astype(np.uint8)))
+            ora.reset(scen, idx, mask=d)
+            _compare_with_oracle(env, ora, cfg, (ep, t, "masked reset"))
+    assert env.error_report() == (0, 0)
+    env.close()
+
+
 def _full_size_properties(cfg, pool, N, n_small, steps, frames_fixed):
     """Batch-composition independence, domain invariants and determinism at a BASELINE batch size."""
     big, small = _vec(N, cfg, pool), _vec(n_small, cfg, pool)

@@ -57,6 +57,12 @@ def test_hip_matches_reference_episode(name):
             assert got.shape[1:] == ref.shape
             for e in envs:
                 assert close(got[e], ref).all(), (name, t, e, ln, np.abs(got[e] - ref).max())
+        for a in cfg.aux:                           # LaserSensor / LeaderTrackDetector_vector / _radar
+            got = env.aux_view(a.name).cpu().numpy()
+            ref = z[tag + ":aux:" + a.name] if t is None else z[tag + ":aux:" + a.name][t]
+            assert got.shape[1:] == ref.shape, (a.name, got.shape, ref.shape)
+            for e in envs:
+                assert close(got[e], ref).all(), (name, t, e, a.name, np.abs(got[e] - ref).max())
         for name, _k in cfg.follower_info:          # FollowerInfo (SEN:822-845), host-side from the device state
             fref = z[tag + ":finfo:" + name] if t is None else z[tag + ":finfo:" + name][t]
             got = env.follower_info(name).cpu().numpy()
@@ -89,7 +95,8 @@ def test_hip_matches_reference_episode(name):
         assert ei[abi.EI_ERROR] == 0
         if "dbg:trk" in z:
             tr = z["dbg:trk"][t]
-            assert int(tr[0]) == ei[abi.EI_TRK_COUNTER] and int(tr[1]) == ei[abi.EI_CORR_HI] - ei[abi.EI_CORR_LO], (name, t, tr, ei)
+            n_hist = ei[abi.EI_HIST1_LEN] if cfg.c.has_tracker == 1 else ei[abi.EI_CORR_HI] - ei[abi.EI_CORR_LO]
+            assert int(tr[0]) == ei[abi.EI_TRK_COUNTER] and int(tr[1]) == n_hist and int(tr[2]) == ei[abi.EI_CORR_HI] - ei[abi.EI_CORR_LO], (name, t, tr, ei)
             hist, corr = env.tracker_obs(last)
             assert np.allclose(hist, z["dbg:hist"][t][:int(tr[1])], rtol=0, atol=1e-9), (name, t, "tracker history")
             assert np.allclose(corr.reshape(-1, 4), z["dbg:corr"][t][:int(tr[2])], rtol=0, atol=1e-9), (name, t, "corridor")

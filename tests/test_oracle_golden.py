@@ -27,6 +27,10 @@ def test_oracle_matches_reference_episode(name):
             ref = z[tag + ":laser:" + ln] if t is None else z[tag + ":laser:" + ln][t]
             assert obs[ln].shape == ref.shape
             assert close(obs[ln], ref).all(), (name, t, ln, np.abs(obs[ln] - ref).max())
+        for a in cfg.aux:                      # LaserSensor / LeaderTrackDetector_vector / _radar (float32 arrays)
+            ref = z[tag + ":aux:" + a.name] if t is None else z[tag + ":aux:" + a.name][t]
+            assert obs[a.name].shape == ref.shape, (name, a.name, obs[a.name].shape, ref.shape)
+            assert close(obs[a.name], ref).all(), (name, t, a.name, np.abs(obs[a.name] - ref).max(), np.argwhere(~close(obs[a.name], ref))[:4])
 
     check_obs("reset", None, obs)
     assert np.array_equal(obs["target"], z["reset:target"])
