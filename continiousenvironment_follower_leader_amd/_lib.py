@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libftl_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", "ftl_abi.hip"), os.path.join(_PKG, "csrc", "ftl_device.hpp"),
-           os.path.join(_PKG, "csrc", "ftl_frames_group.hpp"), os.path.join(_PKG, "csrc", "ftl_aux.hpp"), os.path.join(_PKG, "csrc", "ftl_scenario.cpp"),
+           os.path.join(_PKG, "csrc", "ftl_frames_group.hpp"), os.path.join(_PKG, "csrc", "ftl_aux.hpp"), os.path.join(_PKG, "csrc", "ftl_gazebo.hpp"), os.path.join(_ROOT, "include", "ftl_gazebo.h"), os.path.join(_PKG, "csrc", "ftl_scenario.cpp"),
            os.path.join(_ROOT, "include", "ftl.h")]
 # translation units: the device code + C-ABI, and the host-only scenario generator (reset-time, no GPU code)
 UNITS = [os.path.join(_PKG, "csrc", "ftl_abi.hip"), os.path.join(_PKG, "csrc", "ftl_scenario.cpp")]
@@ -75,6 +75,18 @@ def load():
                                            C.POINTER(abi.Scenarios), vp]
     lib.ftl_generate_scenarios.restype = C.c_int
     lib.ftl_sizeof_scen_params.restype = C.c_size_t
+    # include/ftl_gazebo.h
+    lib.ftl_gz_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    lib.ftl_gz_destroy.argtypes = [vp]
+    lib.ftl_gz_destroy.restype = None
+    lib.ftl_gz_state_bytes.argtypes = [vp]
+    lib.ftl_gz_state_bytes.restype = C.c_size_t
+    lib.ftl_gz_bind_state.argtypes = [vp, vp, C.c_size_t]
+    lib.ftl_gz_lasers_len.argtypes = [vp]
+    lib.ftl_gz_lasers_len.restype = i32
+    lib.ftl_gz_reset.argtypes = [vp, vp, vp]
+    lib.ftl_gz_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ftl_gz_state_field.argtypes = [vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(i32)]
     for n in ("ftl_sizeof_config", "ftl_sizeof_scenarios", "ftl_sizeof_outputs"):
         getattr(lib, n).restype = C.c_size_t
     _LIB = lib
@@ -83,7 +95,9 @@ def load():
 
 EXPORTS = ("ftl_create", "ftl_destroy", "ftl_lasers_len", "ftl_get_config", "ftl_state_bytes", "ftl_bind_state",
            "ftl_state_field", "ftl_load_scenarios", "ftl_reset", "ftl_step", "ftl_last_error", "ftl_generate_scenarios",
-           "ftl_episode_metrics", "ftl_kernel_timing", "ftl_kernel_times")
+           "ftl_episode_metrics", "ftl_kernel_timing", "ftl_kernel_times",
+           "ftl_gz_create", "ftl_gz_destroy", "ftl_gz_state_bytes", "ftl_gz_bind_state", "ftl_gz_lasers_len", "ftl_gz_reset", "ftl_gz_step",
+           "ftl_gz_state_field")
 
 
 def check(rc, lib=None):

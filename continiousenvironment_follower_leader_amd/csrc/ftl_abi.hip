@@ -444,6 +444,8 @@ int ftl_episode_metrics(ftl_handle* h, double* dev_metrics, int32_t* dev_errors,
 
 }  // extern "C"
 
+#include "ftl_gazebo.hpp"      // follower-relative tracker / ray sensors (include/ftl_gazebo.h), same translation unit
+
 #ifdef FTL_PROFILE_PATHS
 extern "C" int ftl_debug_wave_times(unsigned long long* out) {
     hipDeviceSynchronize();

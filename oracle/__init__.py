@@ -2,4 +2,4 @@
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
 package (see oracle/ftl_oracle.c for the pinning statement)."""
-from .oracle import OracleEnv, build_oracle, load_oracle  # noqa: F401
+from .oracle import OracleEnv, OracleGazebo, build_oracle, load_oracle  # noqa: F401

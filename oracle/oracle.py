@@ -15,9 +15,9 @@ _LIB = None
 
 def build_oracle(force=False):
     so = os.path.join(_HERE, "libftl_oracle.so")
-    src = os.path.join(_HERE, "ftl_oracle.c")
-    hdr = os.path.join(_HERE, "..", "include", "ftl.h")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [os.path.join(_HERE, "ftl_oracle.c"), os.path.join(_HERE, "ftl_oracle_gazebo.c"), os.path.join(_HERE, "..", "include", "ftl.h"),
+            os.path.join(_HERE, "..", "include", "ftl_gazebo.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libftl_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -39,6 +39,13 @@ def load_oracle():
         lib.ftlo_get_traj.argtypes = [vp, vp, C.c_int]
         lib.ftlo_set_env_id.argtypes = [vp, C.c_int]
         lib.ftlo_step_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+        lib.ftlo_gz_create.restype = C.c_void_p
+        lib.ftlo_gz_create.argtypes = [vp]
+        lib.ftlo_gz_destroy.argtypes = [vp]
+        lib.ftlo_gz_reset.argtypes = [vp]
+        lib.ftlo_gz_lasers_len.argtypes = [vp]
+        lib.ftlo_gz_step.argtypes = [vp, vp, C.c_double, vp, vp, vp, C.c_int, vp]
+        lib.ftlo_gz_get.argtypes = [vp, vp, vp, vp]
         _LIB = lib
     return _LIB
 
@@ -115,3 +122,32 @@ class OracleEnv:
         buf = np.zeros((self.cfg.c.traj_cap, 2), np.float32)
         n = self.lib.ftlo_get_traj(self.h, _p(buf), self.cfg.c.traj_cap)
         return buf[:n]
+
+
+class OracleGazebo:
+    """One follower-relative tracker + its ray sensors (oracle/ftl_oracle_gazebo.c).  ``cfg`` is a ``gazebo.GzConfig`` ctypes struct."""
+
+    def __init__(self, cfg):
+        self.lib = load_oracle()
+        self.cfg = cfg
+        self.h = self.lib.ftlo_gz_create(C.byref(cfg))
+        self.lasers = np.zeros(max(self.lib.ftlo_gz_lasers_len(self.h), 1), np.float32)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ftlo_gz_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.lib.ftlo_gz_reset(self.h)
+
+    def step(self, leader, yaw, delta, pts1, pts2):
+        leader = np.ascontiguousarray(leader, np.float64); delta = np.ascontiguousarray(delta, np.float64)
+        p1 = np.ascontiguousarray(pts1, np.float64).reshape(-1, 2); p2 = np.ascontiguousarray(pts2, np.float64).reshape(-1, 2)
+        self.lib.ftlo_gz_step(self.h, _p(leader), float(yaw), _p(delta), _p(p1), _p(p2), len(p1), _p(self.lasers))
+        return self.lasers.copy()
+
+    def state(self):
+        cnt = np.zeros(4, np.int32); hist = np.zeros((64, 2)); corr = np.zeros((64, 4))
+        self.lib.ftlo_gz_get(self.h, _p(cnt), _p(hist), _p(corr))
+        return dict(counter=int(cnt[0]), hist=hist[:cnt[1]].copy(), corr=corr[:cnt[2]].copy(), error=int(cnt[3]))

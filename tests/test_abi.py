@@ -18,7 +18,7 @@ def lib():
 
 
 def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "ftl.h")).read()
+    src = open(os.path.join(ROOT, "include", "ftl.h")).read() + open(os.path.join(ROOT, "include", "ftl_gazebo.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     inline = set(re.findall(r"static\s+inline\s+[\w\s]+?\b(ftl_\w+)\s*\(", src))      # header-only helpers, not exports
     return sorted(set(re.findall(r"\b(ftl_[a-z_]+)\s*\(", src)) - inline)
