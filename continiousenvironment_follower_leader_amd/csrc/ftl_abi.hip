@@ -149,6 +149,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         a.out_offset = off; off += a.out_len;
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
+    if (rays > 1023) { delete h; return fail(FTL_E_INVALID, "more than 1023 rays per env (the candidate list of the ray kernel packs a ray index into 10 bits)"); }
     if (hmax * (P.R - 1) > FTL_WAVE) { delete h; return fail(FTL_E_INVALID, "max_prev_obs x (1 + bears) exceeds one wavefront of snapshot rects"); }
     {   // row width / common history of the fused sensorPrev output: the sensors wrappers.py:204, 214 select (in_policy_obs), in dict order
         int w = 0, hcommon = 0;
@@ -181,7 +182,9 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         // + ray ends (double2) + per-(ray, snapshot) minima (u64 x HM) + miss readings (f64)
         const size_t rects = (size_t)cfg->n_static + hmax + (size_t)hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
         P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + rects * 20 + (size_t)2 * cfg->corr_cap * 4 + (size_t)2 * hmax * 20 + 64
-                           + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : FTL_HMAX) * 8      /* >= the HM of whichever instantiation launch() picks */ + (size_t)rays * 8);
+                           + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : FTL_HMAX) * 8      /* >= the HM of whichever instantiation launch() picks */ + (size_t)rays * 8
+                           + (size_t)FTL_PAIR_CAP * 4 + 16     /* candidate list of phase 3 + its counter */
+                           + rects * 8 + 32);                 /* facing-edge list (u16 x 4 per rect) + edge counters */
     }
     if (P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
     *out = h;

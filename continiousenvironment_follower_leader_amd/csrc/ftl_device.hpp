@@ -28,7 +28,16 @@
 
 #define FTL_WAVE 64
 #define FTL_HMAX 12         // compile-time cap on max_prev_obs (the shipped training configs use 10)
-#define FTL_WIDE_ARC 8       // segments facing more candidate rays than this are tested by the whole wavefront, one ray per lane
+#ifndef FTL_RAYS_COMPACT
+#define FTL_RAYS_COMPACT 0   // (measured slower) phase 3 gathers its (segment, ray) candidates in an LDS list and tests them densely, 64 per pass
+#endif
+#if FTL_RAYS_COMPACT
+#define FTL_WIDE_ARC 4       // segments facing more candidate rays than this are tested by the whole wavefront, one ray per lane
+#define FTL_PAIR_CAP 320     // candidate list: a chunk adds at most 64 * FTL_WIDE_ARC entries, flushed once fewer than that many are free
+#else
+#define FTL_WIDE_ARC 8
+#define FTL_PAIR_CAP 0
+#endif
 #ifndef FTL_RAYS_WPE
 #define FTL_RAYS_WPE 6      // 80 VGPRs without spills; LDS (7 KB per env) caps the CU at ~22 waves, i.e. 5.5 per SIMD
 #endif
@@ -338,7 +347,9 @@ __device__ __forceinline__ float arc_atan2(float y, float x) {
     const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
     const float a = hi > 0.0f ? __fdividef(lo, hi) : 0.0f;
     const float t = a * a;
-    float r = a * (0.9998660f + t * (-0.3302995f + t * (0.1801410f + t * (-0.0851330f + t * 0.0208351f))));
+    // (explicit fma: the translation unit is compiled with -ffp-contract=off for the code that follows the reference operation by
+    //  operation; this value only selects candidate rays, see above)
+    float r = a * __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, 0.0208351f, -0.0851330f), 0.1801410f), -0.3302995f), 0.9998660f);
     r = ay > ax ? 1.5707963267948966f - r : r;
     r = x < 0.0f ? 3.141592653589793f - r : r;
     return y < 0.0f ? -r : r;
@@ -398,11 +409,15 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     unsigned* s_rmask = reinterpret_cast<unsigned*>(s_green + cap_gr);           // [cap_rs + cap_rd]
     unsigned* s_cref = s_rmask + cap_rs + cap_rd;                                // [cap_cr]: p & cmask | side << 15 | mask << 16
     unsigned* s_gmask = s_cref + cap_cr;                                         // [cap_gr]
-    int* s_cnt = reinterpret_cast<int*>(s_gmask + cap_gr);                       // [SEG_CLASSES]
-    const int n_u32 = (cap_rs + cap_rd) + cap_cr + cap_gr + 4;                   // words since the last 16-byte aligned array
+    int* s_cnt = reinterpret_cast<int*>(s_gmask + cap_gr);                       // [SEG_CLASSES] table entries per class, then [2] visible edges of the rect classes
+    int* s_ecnt = s_cnt + SEG_CLASSES;
+    unsigned short* s_edge = reinterpret_cast<unsigned short*>(s_cnt + 8);       // [4 * (cap_rs + cap_rd)]: rect slot << 2 | edge, the edges facing the follower
+    const int n_u32 = (cap_rs + cap_rd) + cap_cr + cap_gr + 8 + 2 * (cap_rs + cap_rd);   // words since the last 16-byte aligned array
     double2* s_ray = reinterpret_cast<double2*>(s_rmask + ((n_u32 + 3) & ~3));     // 16-byte aligned [total_rays]
     unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [total_rays][HM]
     double* s_miss = reinterpret_cast<double*>(s_best + (size_t)P.total_rays * HM);                     // [total_rays] |ray end - origin|
+    unsigned* s_pair = reinterpret_cast<unsigned*>(s_miss + P.total_rays);                              // [FTL_PAIR_CAP] ray | class << 10 | index << 12
+    int* s_np = reinterpret_cast<int*>(s_pair + FTL_PAIR_CAP);                                          // entries in s_pair
     const unsigned long long kInfBits = 0x7fefffffffffffffull;                                       // DBL_MAX: "no hit"
 
     // Round trip 1: everything that is addressed by the env index alone is requested at once -- the scalars, every ring slot
@@ -463,7 +478,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         continue;
 #endif
         __syncthreads();
-        if (lane < SEG_CLASSES) s_cnt[lane] = 0;
+        if (lane < SEG_CLASSES + 2) s_cnt[lane] = 0;
         for (int p = umin + lane; p < umax; p += FTL_WAVE) {
             const double* q = corr_slot(P, env, p);
             s_corr[p & cmask] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
@@ -477,11 +492,21 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         // ---- phase 1: culled, compacted segment table; sources flattened: statics | snapshot rects | corridor points | caps
         const float reach = lmax + 2.0f;
         const float bx0 = cx - reach, bx1 = cx + reach, by0 = cy - reach, by1 = cy + reach;
+        // Only the edges that FACE the follower go to the work list.  A ray that reaches a back-facing edge of an axis-aligned rect
+        // has entered the rect through a facing edge at a smaller distance, and the reference's own test detects that entry unless the
+        // ray passes within rounding (~1e-13 px: the float32 orientation test of an axis-aligned edge is an exact sign test, the
+        // others are float64) of a corner -- so the minimum over the facing edges IS the reference's minimum over all four.  A
+        // follower inside or on the rect keeps all four.
         auto push_rect = [&](int cls, int4 q, unsigned sm) {
             if (sm == 0u) return;
-            if ((float)(q.x + q.z) < bx0 || (float)q.x > bx1 || (float)(q.y + q.w) < by0 || (float)q.y > by1) return;
-            int at = (cls == SEG_STATIC ? 0 : cap_rs) + atomicAdd(&s_cnt[cls], 1);
-            s_rect[at] = q; s_rmask[at] = sm;
+            const float l = (float)q.x, t = (float)q.y, r = (float)(q.x + q.z), b = (float)(q.y + q.w);
+            if (r < bx0 || l > bx1 || b < by0 || t > by1) return;
+            const int slot = (cls == SEG_STATIC ? 0 : cap_rs) + atomicAdd(&s_cnt[cls], 1);
+            s_rect[slot] = q; s_rmask[slot] = sm;
+            unsigned em = (cy > b ? 1u : 0u) | (cx > r ? 2u : 0u) | (cy < t ? 4u : 0u) | (cx < l ? 8u : 0u);      // edge order of sensors.py:668-671
+            if (em == 0u) em = 15u;
+            int at = (cls == SEG_STATIC ? 0 : 4 * cap_rs) + atomicAdd(&s_ecnt[cls], __popc(em));
+            while (em) { const int e = __ffs(em) - 1; em &= em - 1; s_edge[at++] = (unsigned short)((slot << 2) | e); }
         };
         auto push_corr = [&](int p, int side, float ax, float ay, float bx, float by, unsigned sm) {
             if (fmaxf(ax, bx) < bx0 || fminf(ax, bx) > bx1 || fmaxf(ay, by) < by0 || fminf(ay, by) > by1) return;
@@ -562,13 +587,64 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             FTL_FOR_LASERS(k) {
                 if (c.lasers[k].after_tracker != which) continue;
                 const int ro = c.lasers[k].react_obstacles;
-                if (ro == 1 || ro == 2) n_items += 4 * s_cnt[SEG_STATIC];      // 4 edges per rect
-                if (ro == 1 || ro == 3) n_items += 4 * s_cnt[SEG_DYNAMIC];
+                if (ro == 1 || ro == 2) n_items += s_ecnt[SEG_STATIC];         // the edges that face the follower (1-2 per rect)
+                if (ro == 1 || ro == 3) n_items += s_ecnt[SEG_DYNAMIC];
                 if (c.lasers[k].react_corridor) n_items += s_cnt[SEG_CORRIDOR];
                 if (c.lasers[k].react_green) n_items += s_cnt[SEG_GREEN];
             }
+            // table entry (class mq, index m) -> segment + mask of the snapshots that contain it
+            auto fetch = [&](int mq, int m, float4& sg, unsigned& sm) {
+                if (mq < 2) {                                // a facing edge of a near rect; edges in the order of sensors.py:668-671
+                    const int ent = s_edge[(mq == SEG_STATIC ? 0 : 4 * cap_rs) + m];
+                    const int at = ent >> 2;
+                    const int4 q = s_rect[at]; sm = s_rmask[at];
+                    const float l = (float)q.x, t = (float)q.y, r = (float)(q.x + q.z), b = (float)(q.y + q.w);
+                    const int e = ent & 3;
+                    sg = e == 0 ? make_float4(l, b, r, b) : e == 1 ? make_float4(r, t, r, b) : e == 2 ? make_float4(r, t, l, t) : make_float4(l, b, l, t);
+                } else if (mq == SEG_CORRIDOR) {             // polyline segment p -> p+1 of the right (0) / left (1) border
+                    const unsigned ref = s_cref[m];
+                    const int p = ref & 0x7fff; sm = ref >> 16;
+                    const float4 u = s_corr[p], v = s_corr[(p + 1) & cmask];
+                    sg = (ref >> 15) & 1u ? make_float4(u.z, u.w, v.z, v.w) : make_float4(u.x, u.y, v.x, v.y);
+                } else { sg = s_green[m]; sm = s_gmask[m]; }
+            };
+            // the reference's intersection test of ray `ray` (index into s_ray / s_best) with segment sgx
+            auto test = [&](int ray, const float4& sgx, unsigned smx) {
+                const double2 e = s_ray[ray];
+                double d2;
+                if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sgx, d2)) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
+#pragma unroll
+                    for (int j = 0; j < HM; j++) if ((smx >> j) & 1u) atomicMin(&s_best[ray * HM + j], bits);
+                }
+            };
+#if FTL_RAYS_COMPACT
+            // Most table entries face no ray at all and few face more than one (46 candidates per env-step in ~106 entries on the bench
+            // workload): testing them where they are found keeps 13 % of the lanes busy.  The candidates go to a list instead and are
+            // tested 64 at a time.
+            if (lane == 0) *s_np = 0;
+            auto flush = [&]() {
+                __syncthreads();
+                const int np = __builtin_amdgcn_readfirstlane(*s_np);
+                for (int p0 = 0; p0 < np; p0 += FTL_WAVE) {
+                    const int p = p0 + lane;
+                    if (p < np) {
+                        const unsigned rec = s_pair[p];
+                        float4 sgp; unsigned smp;
+                        fetch((int)((rec >> 10) & 3u), (int)(rec >> 12), sgp, smp);
+                        test((int)(rec & 1023u), sgp, smp);
+                    }
+                }
+                __syncthreads();
+                if (lane == 0) *s_np = 0;
+                __syncthreads();
+            };
+#endif
             for (int w0 = 0; w0 < n_items; w0 += FTL_WAVE) {
                 const int w = w0 + lane;
+#if FTL_RAYS_COMPACT
+                if (w0 > 0) { __syncthreads(); if (__builtin_amdgcn_readfirstlane(*s_np) > FTL_PAIR_CAP - FTL_WAVE * FTL_WIDE_ARC) flush(); }
+#endif
                 // decode w -> (sensor k, class q, index m within the class); per-lane sensor parameters
                 int m = -1, mq = 0, N = 1, rbase = 0; float lenf = 0.0f, phi0 = 0.0f; bool expl = false;
                 {
@@ -579,7 +655,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                         const bool on[SEG_CLASSES] = { ro == 1 || ro == 2, ro == 1 || ro == 3, c.lasers[k].react_corridor != 0, c.lasers[k].react_green != 0 };
 #pragma unroll
                         for (int q = 0; q < SEG_CLASSES; q++) {
-                            const int cq = on[q] ? (q < 2 ? 4 * s_cnt[q] : s_cnt[q]) : 0;
+                            const int cq = on[q] ? (q < 2 ? s_ecnt[q] : s_cnt[q]) : 0;
                             if (m < 0 && rem >= 0 && rem < cq && w < n_items) {
                                 m = rem; mq = q; N = c.lasers[k].count; rbase = rb; lenf = (float)c.lasers[k].length;
                                 phi0 = (float)((fdir + c.lasers[k].angle_offset) * kDeg2Rad); expl = EXPL && c.lasers[k].explicit_angles != 0;
@@ -594,33 +670,23 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 float4 sg = make_float4(0.f, 0.f, 0.f, 0.f); unsigned sm = 0;
                 const float fN = (float)N;
                 if (m >= 0) {
-                    if (mq < 2) {                                // edge (m & 3) of a near rect, in the order of sensors.py:668-671
-                        const int at = (mq == SEG_STATIC ? 0 : cap_rs) + (m >> 2);
-                        const int4 q = s_rect[at]; sm = s_rmask[at];
-                        const float l = (float)q.x, t = (float)q.y, r = (float)(q.x + q.z), b = (float)(q.y + q.w);
-                        const int e = m & 3;
-                        sg = e == 0 ? make_float4(l, b, r, b) : e == 1 ? make_float4(r, t, r, b) : e == 2 ? make_float4(r, t, l, t) : make_float4(l, b, l, t);
-                    } else if (mq == SEG_CORRIDOR) {             // polyline segment p -> p+1 of the right (0) / left (1) border
-                        const unsigned ref = s_cref[m];
-                        const int p = ref & 0x7fff; sm = ref >> 16;
-                        const float4 u = s_corr[p], v = s_corr[(p + 1) & cmask];
-                        sg = (ref >> 15) & 1u ? make_float4(u.z, u.w, v.z, v.w) : make_float4(u.x, u.y, v.x, v.y);
-                    } else { sg = s_green[m]; sm = s_gmask[m]; }
+                    fetch(mq, m, sg, sm);
                     // candidate rays: the arc [uA, uB] the segment subtends, in units of the ray spacing from ray 0
                     const float inv_step = fN * 0.15915494309189535f;          // N / (2 pi)
                     float ax = sg.x - cx, ay = sg.y - cy, bx = sg.z - cx, by = sg.w - cy;
-                    float uA = (arc_atan2(ay, ax) - phi0) * inv_step, uB = (arc_atan2(by, bx) - phi0) * inv_step;
+                    const float phis = phi0 * inv_step;
+                    float uA = __builtin_fmaf(arc_atan2(ay, ax), inv_step, -phis), uB = __builtin_fmaf(arc_atan2(by, bx), inv_step, -phis);
                     const float invN = __fdividef(1.0f, fN);
-                    uA -= floorf(uA * invN) * fN; uB -= floorf(uB * invN) * fN;      // into [0, N) (an ulp outside is absorbed by the wrap below)
+                    uA = __builtin_fmaf(-floorf(uA * invN), fN, uA); uB = __builtin_fmaf(-floorf(uB * invN), fN, uB);      // into [0, N) (an ulp outside is absorbed by the wrap below)
                     float diff = uB - uA; if (diff < 0.0f) diff += fN;
                     float start = uA, wd = diff;
                     if (diff > 0.5f * fN) { start = uB; wd = fN - diff; }
-                    // closest approach of the segment to the follower
+                    // closest approach of the segment to the follower (culling only: 2 px of slack below)
                     float ex_ = bx - ax, ey_ = by - ay;
-                    float l2 = ex_ * ex_ + ey_ * ey_;
-                    float tt = l2 > 0.0f ? fminf(fmaxf(__fdividef(-(ax * ex_ + ay * ey_), l2), 0.0f), 1.0f) : 0.0f;   // culling only: 2 px of slack below
-                    float nx = ax + tt * ex_, ny = ay + tt * ey_;
-                    float dmin2 = nx * nx + ny * ny;
+                    float l2 = __builtin_fmaf(ex_, ex_, ey_ * ey_);
+                    float tt = l2 > 0.0f ? fminf(fmaxf(__fdividef(-__builtin_fmaf(ax, ex_, ay * ey_), l2), 0.0f), 1.0f) : 0.0f;
+                    float nx = __builtin_fmaf(tt, ex_, ax), ny = __builtin_fmaf(tt, ey_, ay);
+                    float dmin2 = __builtin_fmaf(nx, nx, ny * ny);
                     const float reachf = lenf + 2.0f;
                     if (dmin2 > reachf * reachf) { i0 = 0; cnt = 0; }                     // wholly beyond this sensor's reach
                     else if (expl || dmin2 < 4.0f || wd > 0.5f * fN - 0.05f) { i0 = 0; cnt = N; }   // through / next to the origin, or rays
@@ -633,20 +699,13 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     }
                 }
                 FTL_RTIC(4);
+#if defined(FTL_RAYS_STOP) && (FTL_RAYS_STOP == 5 || FTL_RAYS_STOP == 6)   // diagnostic: decode + fetch (+ arc for 5) only, no ray tests
+                if (FTL_RAYS_STOP == 6) cnt = (int)(sg.x + sg.y + sg.z + sg.w) == 0x7fffffff ? 1 : 0; else cnt = cnt == 0x7fffffff ? 1 : 0;
+#endif
 #ifdef FTL_PROFILE_RAYS
                 if (threadIdx.x == 0) { s_rcyc[8] += 1; }
                 { int mc = cnt; for (int o = 32; o >= 1; o >>= 1) mc = max(mc, __shfl_xor(mc, o)); int ni = __popcll(__ballot(m >= 0)); int sc = cnt; for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o); int n4 = __popcll(__ballot(cnt > 4)); if (threadIdx.x == 0) { s_rcyc[9] += mc; s_rcyc[10] += sc; s_rcyc[11] += ni; s_rcyc[12] += (mc <= 2); s_rcyc[13] += (mc > 2 && mc <= 4); s_rcyc[14] += (mc > 4 && mc <= 8); s_rcyc[15] += (mc > 8); } (void)n4; }
 #endif
-                // the reference's intersection test of ray `ray` (index into s_ray / s_best) with segment sgx
-                auto test = [&](int ray, const float4& sgx, unsigned smx) {
-                    const double2 e = s_ray[ray];
-                    double d2;
-                    if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sgx, d2)) {
-                        const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
-#pragma unroll
-                        for (int j = 0; j < HM; j++) if ((smx >> j) & 1u) atomicMin(&s_best[ray * HM + j], bits);
-                    }
-                };
                 // A segment next to the follower faces many rays (up to all N): one lane looping over them would hold the
                 // whole wavefront for that many test iterations.  Such segments (rare: a few per cent of the chunks) are
                 // handed to the wavefront instead -- broadcast the segment, one ray per lane.
@@ -664,11 +723,25 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     }
                 }
                 const int own = cnt > FTL_WIDE_ARC ? 0 : cnt;
+#if FTL_RAYS_COMPACT
+                if (own > 0) {
+                    const int pos = atomicAdd(s_np, own);
+                    const unsigned rec = ((unsigned)mq << 10) | ((unsigned)m << 12);
+                    for (int t = 0; t < own; t++) {
+                        int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
+                        s_pair[pos + t] = rec | (unsigned)(rbase + i);
+                    }
+                }
+#else
                 for (int t = 0; t < own; t++) {
                     int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
                     test(rbase + i, sg, sm);
                 }
+#endif
             }
+#if FTL_RAYS_COMPACT
+            flush();
+#endif
         }
         FTL_RTIC(5);
 #if defined(FTL_RAYS_STOP) && FTL_RAYS_STOP == 4
