@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--kernel-steps", type=int, default=100, help="steps of the per-kernel HIP-event pass after the timed region")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--workload", default="B", choices=["B", "D", "E", "F"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the metrics all-reduce: nccl (= RCCL over xGMI, one GPU per rank) or gloo -- a rehearsal "
+                         "of the N > 1 path on a box with fewer GPUs than ranks (every rank then uses GPU rank %% n_visible)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,8 +162,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -209,7 +216,11 @@ def main():
     n_err, err_bits = env.error_report()
     tmax = torch.tensor([dt, float(n_err)], dtype=torch.float64, device=device)
     if dist is not None:
-        dist.all_reduce(tmax[:1], op=dist.ReduceOp.MAX)
+        if a.backend == "gloo":                      # gloo reduces host tensors
+            tmax, metrics = tmax.cpu(), metrics.cpu()
+        tm = tmax[:1].clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        tmax[0] = tm[0]
         shard.reduce_metrics(metrics)
         errs = tmax[1:].clone()
         dist.all_reduce(errs, op=dist.ReduceOp.SUM)
@@ -259,7 +270,7 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_text % (n, pool.n), "workload_id": a.workload,
-                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "independent env shards x%d" % world,
+                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "independent env shards x%d%s" % (world, " (gloo rehearsal)" if (world > 1 and a.backend == "gloo") else ""),
                        "age_steps": a.age,
                        "episode_metrics": dict(zip(shard.METRIC_NAMES, m)),
                        "mean_return": m[1] / m[0] if m[0] else None, "mean_episode_frames": m[2] / m[0] if m[0] else None,

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include <cstdlib>
+#include <cmath>
 
 #include "ftl_device.hpp"
 #include "ftl_frames_group.hpp"
@@ -21,7 +22,7 @@ thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct Field { const char* name; size_t offset, per_env; int dtype; };
-constexpr int FTL_N_FIELDS = 13;
+constexpr int FTL_N_FIELDS = 14;
 
 }  // namespace
 
@@ -149,6 +150,23 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         a.out_offset = off; off += a.out_len;
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;
+    {   // ray directions relative to the heading (glibc cos / sin, as the reference's np.cos(np.radians(.))) and the no-hit reading
+        const double deg2rad = 3.141592653589793 / 180.0;
+        int g = 0; bool miss_ok = true;
+        const double span = (double)(cfg->width > cfg->height ? cfg->width : cfg->height);
+        const double margin = 1e-11 * (span > 2048.0 ? span / 2048.0 : 1.0);
+        for (int k = 0; k < cfg->n_lasers; k++) {
+            const ftl_laser_cfg& l = cfg->lasers[k];
+            for (int i = 0; i < l.count && g < FTL_MAX_RAYS; i++, g++) {
+                const double a = l.explicit_angles ? l.ray_angles[i & 7] : l.angle_offset + i * (360.0 / (double)l.count);
+                P.ray_rot[g][0] = cos(a * deg2rad); P.ray_rot[g][1] = sin(a * deg2rad);
+            }
+            // float64 |end - origin| = laser_length within 4e-13 (coordinates < 2048): float32(.) is float32(laser_length) unless a
+            // rounding boundary of float32 lies that close
+            miss_ok = miss_ok && (float)(l.length - margin) == (float)l.length && (float)(l.length + margin) == (float)l.length;
+        }
+        P.miss_const = miss_ok ? 1 : 0;
+    }
     if (rays > 1023) { delete h; return fail(FTL_E_INVALID, "more than 1023 rays per env (the candidate list of the ray kernel packs a ray index into 10 bits)"); }
     if (hmax * (P.R - 1) > FTL_WAVE) { delete h; return fail(FTL_E_INVALID, "max_prev_obs x (1 + bears) exceeds one wavefront of snapshot rects"); }
     {   // row width / common history of the fused sensorPrev output: the sensors wrappers.py:204, 214 select (in_policy_obs), in dict order
@@ -170,7 +188,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         {"hist", (size_t)cfg->corr_cap * 2, 2, 8}, {"corr", (size_t)cfg->corr_cap * 4, 2, 8},
         {"snap_rects", (size_t)hmax * (P.R - 1) * 4, 0, 4}, {"snap_win", (size_t)hmax * 4, 0, 4},
         {"traj_bb", (size_t)(cfg->traj_cap / FTL_TRAJ_BLOCK) * 4, 1, 4}, {"ep_stats", FTL_N_METRICS, 2, 8},
-        {"hist1", (size_t)(cfg->has_tracker == 1 ? cfg->hist1_cap : 0) * 2, 1, 4}};
+        {"hist1", (size_t)(cfg->has_tracker == 1 ? cfg->hist1_cap : 0) * 2, 1, 4}, {"fol_cs", 2, 2, 8}};
     size_t cur = 0;
     for (int i = 0; i < FTL_N_FIELDS; i++) {
         cur = align_up(cur, 256);
@@ -237,7 +255,7 @@ int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes) {
     P.hist = (double*)(b + h->fields[6].offset); P.corr = (double*)(b + h->fields[7].offset);
     P.snap_rects = (int32_t*)(b + h->fields[8].offset); P.snap_win = (int32_t*)(b + h->fields[9].offset);
     P.traj_bb = (float*)(b + h->fields[10].offset); P.ep_stats = (double*)(b + h->fields[11].offset);
-    P.hist1 = (float*)(b + h->fields[12].offset);
+    P.hist1 = (float*)(b + h->fields[12].offset); P.fol_cs = (double*)(b + h->fields[13].offset);
     h->bound = true; h->dirty = true;
     return FTL_OK;
 }

@@ -28,6 +28,7 @@
 
 #define FTL_WAVE 64
 #define FTL_HMAX 12         // compile-time cap on max_prev_obs (the shipped training configs use 10)
+#define FTL_MAX_RAYS 1024   // rays per env over all ray sensors (the host rejects more than 1023)
 #ifndef FTL_RAYS_COMPACT
 #define FTL_RAYS_COMPACT 0   // (measured slower) phase 3 gathers its (segment, ray) candidates in an LDS list and tests them densely, 64 per pass
 #endif
@@ -52,6 +53,13 @@ struct FtlDevParams {
     float* traj_bb;                   // [n_envs][traj_cap / FTL_TRAJ_BLOCK][4]: xmin, ymin, xmax, ymax of each block of trajectory points
     double* ep_stats;                 // [n_envs][FTL_N_METRICS]: metrics of the episodes that ended in this env slot (include/ftl.h)
     float* hist1;                     // [n_envs][hist1_cap][2]: position history of the v1 tracker (sensors.py:148-229)
+    double* fol_cs;                   // [n_envs][2]: cos, sin of the follower's direction as the frame kernel leaves it (one sincos per lane
+                                      // there serves 16 envs; here it would be one per ray)
+    // ray directions relative to the follower's heading, host-computed with glibc: (cos, sin) of (first_laser_angle_offset + i * 360 / N)
+    // -- or of ray_angles[i] -- in degrees, indexed by the ray's position over ALL ray sensors in config order
+    double ray_rot[FTL_MAX_RAYS][2];
+    int32_t miss_const;               // 1: a ray without a hit reads float32(laser_length) exactly for every sensor (checked on the host: the
+                                      // value float64 |end - origin| lies within 4e-13 of laser_length, far from a float32 rounding boundary)
     // env regrouping (library-owned; null = envs stay bound to their wavefronts): slot -> env, cost class of the next step,
     // rank inside the block histogram, per-block key histograms
     int32_t* perm; uint8_t* keys; uint16_t* rank; int32_t* bh;
@@ -434,11 +442,14 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     const int eiv = lane < FTL_EI_COUNT ? ei[lane] : 0;
     const int fpv = lane < 2 ? __float_as_int(P.rb_pos[2 * fo + lane]) : 0;
     const int fdv = lane < 2 ? reinterpret_cast<const int*>(P.rb_dbl + fo * FTL_RD_COUNT + FTL_RD_DIRECTION)[lane] : 0;
+    const int fcv = lane < 4 ? reinterpret_cast<const int*>(P.fol_cs + 2 * (size_t)env)[lane] : 0;
     const int scen = __builtin_amdgcn_readlane(eiv, FTL_EI_SCEN), snap_count = __builtin_amdgcn_readlane(eiv, FTL_EI_SNAP_COUNT);
     const int scan_ok = __builtin_amdgcn_readlane(eiv, FTL_EI_SCAN_OK), snap_head = __builtin_amdgcn_readlane(eiv, FTL_EI_SNAP_HEAD);
     const int newest = (snap_head == 0 ? hmax : snap_head) - 1;   // ring slot of the newest snapshot
     const float cx = __int_as_float(__builtin_amdgcn_readlane(fpv, 0)), cy = __int_as_float(__builtin_amdgcn_readlane(fpv, 1));
     const double fdir = __hiloint2double(__builtin_amdgcn_readlane(fdv, 1), __builtin_amdgcn_readlane(fdv, 0));
+    const double fcd = __hiloint2double(__builtin_amdgcn_readlane(fcv, 1), __builtin_amdgcn_readlane(fcv, 0));     // cos / sin of fdir (frame kernel)
+    const double fsd = __hiloint2double(__builtin_amdgcn_readlane(fcv, 3), __builtin_amdgcn_readlane(fcv, 2));
     float* out_base = C.out.lasers + (size_t)env * P.lasers_len;
     const int nsnap = snap_count < hmax ? snap_count : hmax;       // valid snapshots, newest = snap_count-1
     const unsigned all_snaps = (1u << nsnap) - 1u;                  // bit a = age a (nsnap <= 8)
@@ -556,20 +567,25 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             int n_rays = 0;
             FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) n_rays += c.lasers[k].count;
             for (int g = lane; g < n_rays; g += FTL_WAVE) {
-                int i = g; double len = 0, aoff = 0, period = 0; bool found = false; int kk = 0;
-                FTL_FOR_LASERS(k) {
-                    if (c.lasers[k].after_tracker != which) continue;
+                int i = g, gi = 0, gb = 0; double len = 0; bool found = false;
+#pragma unroll
+                for (int k = 0; k < FTL_MAX_LASERS; k++) if (k < c.n_lasers) {       // (every sensor: the rotation table is indexed over all of them)
                     const int N = c.lasers[k].count;
-                    if (!found && i < N) { found = true; kk = k; len = c.lasers[k].length; aoff = c.lasers[k].angle_offset; period = 360.0 / (double)N; }
-                    if (!found) i -= N;
+                    if (c.lasers[k].after_tracker == which && !(EXPL && c.lasers[k].compas)) {
+                        if (!found && i < N) { found = true; len = c.lasers[k].length; gi = gb + i; }
+                        if (!found) i -= N;
+                    }
+                    gb += N;
                 }
-                double s, co;
-                if (EXPL && c.lasers[kk].explicit_angles) { aoff = c.lasers[kk].ray_angles[i]; period = 0.0; }     // SEN:609-632: direction + fixed angle
-                sincos_bounded(((fdir + aoff) + i * period) * kDeg2Rad, s, co);
+                // direction of ray i = heading + offset_i (sensors.py:888-891, 609-632): cos / sin by angle addition from the heading's
+                // (frame kernel) and the offset's (host) -- within 2-3 ulp of the reference's cos(radians(heading + offset_i)), like the
+                // device's own sincos
+                const double2 rot = reinterpret_cast<const double2*>(&P.ray_rot[0][0])[gi];
+                const double co = fcd * rot.x - fsd * rot.y, s = fsd * rot.x + fcd * rot.y;
                 const double ex = (double)cx + co * len, ey = (double)cy + s * len;
                 s_ray[g] = make_double2(ex, ey);
-                const double qx0 = ex - (double)cx, qy0 = ey - (double)cy;
-                s_miss[g] = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0));            // np.linalg.norm(end - position), sensors.py:925-930
+                if (P.miss_const) s_miss[g] = (double)(float)len;                    // np.linalg.norm(end - position), sensors.py:925-930
+                else { const double qx0 = ex - (double)cx, qy0 = ey - (double)cy; s_miss[g] = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0)); }
 #pragma unroll
                 for (int j = 0; j < HM; j++) s_best[g * HM + j] = kInfBits;
             }

@@ -1205,6 +1205,11 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
 #ifndef FTL_ABLATE_SENSORS
     g_sensors<G>(P, E);                                  // ENV:937 / ENV:541 (tracker part of use_sensors)
 #endif
+    if (P.cfg.n_lasers > 0) {     // cos / sin of the follower's heading for the ray kernel: one sincos here serves the 16 envs of the wavefront
+        double s, co;
+        sincos_bounded(E.rb.direction * kDeg2Rad, s, co);
+        if (E.valid && E.r == 1) { P.fol_cs[2 * (size_t)E.env] = co; P.fol_cs[2 * (size_t)E.env + 1] = s; }
+    }
     FTL_TIC(7);
     g_write_obs<G>(P, C, E);                             // ENV:938
     g_store<G>(P, E);
