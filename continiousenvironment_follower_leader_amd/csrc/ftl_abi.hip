@@ -166,6 +166,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
             miss_ok = miss_ok && (float)(l.length - margin) == (float)l.length && (float)(l.length + margin) == (float)l.length;
         }
         P.miss_const = miss_ok ? 1 : 0;
+        P.inv_nrect_dyn = (65536u + (unsigned)(P.R - 1) - 1u) / (unsigned)(P.R - 1);
     }
     if (rays > 1023) { delete h; return fail(FTL_E_INVALID, "more than 1023 rays per env (the candidate list of the ray kernel packs a ray index into 10 bits)"); }
     if (hmax * (P.R - 1) > FTL_WAVE) { delete h; return fail(FTL_E_INVALID, "max_prev_obs x (1 + bears) exceeds one wavefront of snapshot rects"); }

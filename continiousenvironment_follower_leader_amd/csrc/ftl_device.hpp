@@ -1,21 +1,18 @@
-// ftl_device.hpp -- CDNA4 (gfx950) device code of the batched Game.step().
+// ftl_device.hpp -- CDNA4 (gfx950) device code of the batched Game.step(): shared scalar math + the ray kernel.
 //
-// One 64-lane wavefront advances one environment (one 64-thread workgroup per env).  A step() is two launches on
-// the same stream, split where the live state is smallest:
+// A step() is two launches on the same stream, split where the live state is smallest:
 //
-//   ftl_frames_kernel  -- frames_per_step x Game.frame_step (follow_the_leader_continuous_env.py:947-1141), the two
-//       LeaderPositionsTracker_v2 scans of use_sensors (classes.py:263-267, 285-286; sensors.py:243-327), the history
-//       snapshot push of the ray sensors (sensors.py:896-897) and _get_obs (1789-1810):
-//       * robots live on lanes 0..R-1 (0 leader, 1 follower, 2.. bears): controller + f64 sin/cos integrator + integer
-//         hitbox update of AbstractRobot.move() (classes.py:134-182) run once per frame for ALL robots in lock-step,
-//         steering (classes.py:184-215) once for leader + bears;
-//       * integer-rect collision tests put one static obstacle on each lane and reduce with a ballot;
-//       * green-zone window / closest-point searches (1828-1843, 1906-1960) stride the factual trajectory over the
-//         lanes and finish with a wave arg-min.
-//   ftl_rays_kernel -- LeaderCorridor_Prev_lasers_v2.scan (sensors.py:883-962) for every ray sensor: one RAY per lane,
-//       obstacle segments (static rects, H-deep history of dynamic rects, f32 corridor ring) staged in LDS and walked
-//       with wave-uniform control flow (uniform distance culling, LDS broadcast reads); one nearest-hit accumulator
-//       per history snapshot in registers.
+//   ftl_frames_group_kernel (ftl_frames_group.hpp) -- frames_per_step x Game.frame_step (follow_the_leader_continuous_env.py:947-1141),
+//       the two LeaderPositionsTracker_v2 scans of use_sensors (classes.py:263-267, 285-286; sensors.py:243-327), the history snapshot
+//       of the ray sensors (sensors.py:896-897) and _get_obs (1789-1810): G = 4 or 8 lanes per env, 64 / G envs per wavefront, robot r of
+//       an env on lane r of its group, list-shaped work strided over the group.
+//   ftl_rays_kernel (below) -- LeaderCorridor_Prev_lasers_v2.scan (sensors.py:883-962) and its relatives for every ray sensor: one
+//       wavefront per env; obstacle sources culled into a small LDS table (near rects with their FACING edges, references into a float32
+//       copy of the corridor ring, green caps); one (sensor, segment) item per lane works out the arc of rays that can reach its
+//       segment and runs the reference's intersection test for those; nearest squared distance per (ray, snapshot) by a 64-bit LDS
+//       atomic min; rows written sensor by sensor.
+//   ftl_aux_kernel / ftl_tracker1_kernel (ftl_aux.hpp), ftl_gz_kernel (ftl_gazebo.hpp) -- the sensors and the tracker variants outside
+//       the headline configs; launched only when a config has them.
 // No MFMA: there is no dense contraction anywhere on this path.
 //
 // Numerics follow oracle/ftl_oracle.c operation by operation (same dtype flow, explicit fma only where numpy/BLAS
@@ -58,6 +55,7 @@ struct FtlDevParams {
     // ray directions relative to the follower's heading, host-computed with glibc: (cos, sin) of (first_laser_angle_offset + i * 360 / N)
     // -- or of ray_angles[i] -- in degrees, indexed by the ray's position over ALL ray sensors in config order
     double ray_rot[FTL_MAX_RAYS][2];
+    uint32_t inv_nrect_dyn;           // ceil(65536 / (R - 1)): source index / objects per snapshot without an integer division
     int32_t miss_const;               // 1: a ray without a hit reads float32(laser_length) exactly for every sensor (checked on the host: the
                                       // value float64 |end - origin| lies within 4e-13 of laser_length, far from a float32 rounding boundary)
     // env regrouping (library-owned; null = envs stay bound to their wavefronts): slot -> env, cost class of the next step,
@@ -452,7 +450,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     const double fsd = __hiloint2double(__builtin_amdgcn_readlane(fcv, 3), __builtin_amdgcn_readlane(fcv, 2));
     float* out_base = C.out.lasers + (size_t)env * P.lasers_len;
     const int nsnap = snap_count < hmax ? snap_count : hmax;       // valid snapshots, newest = snap_count-1
-    const unsigned all_snaps = (1u << nsnap) - 1u;                  // bit a = age a (nsnap <= 8)
+    const unsigned all_snaps = (1u << nsnap) - 1u;                  // bit a = age a (nsnap <= hmax <= FTL_HMAX = 12)
     const int4* stp = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)scen * c.n_static;
     const int4 stq = lane < c.n_static ? stp[lane] : make_int4(0, 0, 0, 0);     // static rect of this lane (round trip 2)
 
@@ -532,8 +530,8 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             push_rect(SEG_STATIC, stq, lane < c.n_static ? all_snaps : 0u);     // identical in every snapshot
             for (int w = lane + FTL_WAVE; w < c.n_static; w += FTL_WAVE) push_rect(SEG_STATIC, stp[w], all_snaps);
             {   // snapshot rects: lane = ring slot * nrect_dyn + object; the leader (object 0) is a static-class object (it
-                // sits in game_object_list), bears are the dynamic class
-                int slot = lane / nrect_dyn, o = lane - slot * nrect_dyn;
+                // sits in game_object_list), bears are the dynamic class.  (1..5 objects per snapshot: a reciprocal instead of a division)
+                const int slot = (int)(((unsigned)lane * P.inv_nrect_dyn) >> 16), o = lane - slot * nrect_dyn;
                 int a = newest - slot; a += a < 0 ? hmax : 0;
                 push_rect(o == 0 ? SEG_STATIC : SEG_DYNAMIC, dynq, (lane < hmax * nrect_dyn && a < nsnap) ? 1u << a : 0u);
             }
@@ -661,25 +659,33 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
 #if FTL_RAYS_COMPACT
                 if (w0 > 0) { __syncthreads(); if (__builtin_amdgcn_readfirstlane(*s_np) > FTL_PAIR_CAP - FTL_WAVE * FTL_WIDE_ARC) flush(); }
 #endif
-                // decode w -> (sensor k, class q, index m within the class); per-lane sensor parameters
+                // decode w -> (sensor, class mq, index m within the class) + the sensor's parameters.  The flattened list is a sequence of
+                // up to 4 segments per sensor whose ends are wave-uniform: three instructions per segment find the lane's segment and its
+                // start, one select chain per sensor fetches the parameters
                 int m = -1, mq = 0, N = 1, rbase = 0; float lenf = 0.0f, phi0 = 0.0f; bool expl = false;
                 {
-                    int rem = w, rb = 0;
+                    int j = 0, start = 0, end = 0;
                     FTL_FOR_LASERS(k) {
                         if (c.lasers[k].after_tracker != which) continue;
                         const int ro = c.lasers[k].react_obstacles;
                         const bool on[SEG_CLASSES] = { ro == 1 || ro == 2, ro == 1 || ro == 3, c.lasers[k].react_corridor != 0, c.lasers[k].react_green != 0 };
 #pragma unroll
                         for (int q = 0; q < SEG_CLASSES; q++) {
-                            const int cq = on[q] ? (q < 2 ? s_ecnt[q] : s_cnt[q]) : 0;
-                            if (m < 0 && rem >= 0 && rem < cq && w < n_items) {
-                                m = rem; mq = q; N = c.lasers[k].count; rbase = rb; lenf = (float)c.lasers[k].length;
-                                phi0 = (float)((fdir + c.lasers[k].angle_offset) * kDeg2Rad); expl = EXPL && c.lasers[k].explicit_angles != 0;
-                            }
-                            rem -= cq;
+                            end += on[q] ? (q < 2 ? s_ecnt[q] : s_cnt[q]) : 0;        // wave-uniform
+                            const bool past = w >= end;
+                            j += past ? 1 : 0; start = past ? end : start;
                         }
-                        rb += c.lasers[k].count;
                     }
+                    int g4 = 0, rb = 0;
+                    FTL_FOR_LASERS(k) {
+                        if (c.lasers[k].after_tracker != which) continue;
+                        if ((j >> 2) == g4) {
+                            N = c.lasers[k].count; rbase = rb; lenf = (float)c.lasers[k].length;
+                            phi0 = (float)((fdir + c.lasers[k].angle_offset) * kDeg2Rad); expl = EXPL && c.lasers[k].explicit_angles != 0;
+                        }
+                        g4 += 1; rb += c.lasers[k].count;
+                    }
+                    if (w < n_items) { m = w - start; mq = j & 3; }
                 }
                 FTL_RTIC(3);
                 int i0 = 0, cnt = 0;
@@ -781,39 +787,32 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 }
             }
             if (any_pad) __syncthreads();
-            // one (ray, age) pair per lane over all sensors of the group: pair p of sensor k = age * N_k + ray
-            int n_pairs = 0;
-            FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) n_pairs += c.lasers[k].count * c.lasers[k].history;
-            for (int p = lane; p < n_pairs; p += FTL_WAVE) {
-                int q = p, N = 1, H = 1, ooff = 0, rb = 0, poff = 0; bool pad = false, found = false; float flen = 1.0f;
-                {
-                    int rbase = 0;
-                    FTL_FOR_LASERS(k) {
-                        if (c.lasers[k].after_tracker != which) continue;
-                        const int np = c.lasers[k].count * c.lasers[k].history;
-                        if (!found && q < np) {
-                            found = true; N = c.lasers[k].count; H = c.lasers[k].history; ooff = c.lasers[k].out_offset; rb = rbase;
-                            pad = EXPL && c.lasers[k].pad_sectors != 0; flen = (float)c.lasers[k].length; poff = P.pol_off[k];   // python number / float32 array -> float32 division
-                        }
-                        if (!found) q -= np;
-                        rbase += c.lasers[k].count;
-                    }
-                }
-                int a2 = 0;
-#pragma unroll
-                for (int j = 1; j < HM; j++) a2 += (q >= j * N) ? 1 : 0;         // q / N without an integer division (a2 < H <= HM)
-                const int i = q - a2 * N;
+            // one (ray, age) pair per lane, sensor by sensor (the sensor's parameters stay wave-uniform): pair q = age * N + ray
+            int rbase = 0;
+            FTL_FOR_LASERS(k) {
+                const int N = c.lasers[k].count;
+                if (c.lasers[k].after_tracker != which) { continue; }
+                const int H = c.lasers[k].history, ooff = c.lasers[k].out_offset, poff = P.pol_off[k], rb = rbase;
+                const bool pad = EXPL && c.lasers[k].pad_sectors != 0;
+                const float flen = (float)c.lasers[k].length;                       // python number / float32 array -> float32 division
                 const int Wd = pad ? 4 * N : N;
-                int col = i;
-                if (pad) {
-                    const double lis = (double)N / 4.0, di = (double)i;         // lasers_in_sector (sensors.py:938)
-                    col = (di < lis ? 0 : (di < 2 * lis ? 1 : (di < 3 * lis ? 2 : 3))) * N + i;
+                for (int q = lane; q < N * H; q += FTL_WAVE) {
+                    int a2 = 0;
+#pragma unroll
+                    for (int j = 1; j < HM; j++) a2 += (q >= j * N) ? 1 : 0;         // q / N without an integer division (a2 < H <= HM)
+                    const int i = q - a2 * N;
+                    int col = i;
+                    if (pad) {
+                        const double lis = (double)N / 4.0, di = (double)i;         // lasers_in_sector (sensors.py:938)
+                        col = (di < lis ? 0 : (di < 2 * lis ? 1 : (di < 3 * lis ? 2 : 3))) * N + i;
+                    }
+                    const unsigned long long bb = s_best[(rb + i) * HM + a2];
+                    const double v = (a2 < nsnap && bb != kInfBits) ? sqrt(__longlong_as_double((long long)bb)) : s_miss[rb + i];
+                    const float vf = (float)v;
+                    out_base[ooff + (H - 1 - a2) * Wd + col] = vf;
+                    if (pol && poff >= 0) pol[(H - 1 - a2) * P.pol_width + poff + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
                 }
-                const unsigned long long bb = s_best[(rb + i) * HM + a2];
-                const double v = (a2 < nsnap && bb != kInfBits) ? sqrt(__longlong_as_double((long long)bb)) : s_miss[rb + i];
-                const float vf = (float)v;
-                out_base[ooff + (H - 1 - a2) * Wd + col] = vf;
-                if (pol && poff >= 0) pol[(H - 1 - a2) * P.pol_width + poff + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
+                rbase += N;
             }
         }
         FTL_RTIC(6);

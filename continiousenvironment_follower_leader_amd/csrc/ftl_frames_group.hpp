@@ -1,15 +1,15 @@
-// ftl_frames_group.hpp -- frame-loop kernel, second generation: G lanes per environment, 64/G environments per
-// wavefront (G = 4 for up to 2 dynamic obstacles, G = 8 for up to 4).
+// ftl_frames_group.hpp -- the frame-loop kernel: G lanes per environment, 64 / G environments per wavefront (G = 4 for up to 2
+// dynamic obstacles, G = 8 for up to 4).
 //
-// The first-generation kernel (ftl_frames_kernel) gives one env a whole wavefront and spends most of its
-// instructions on per-env scalar work (controller, sin/cos, atan, reward logic) that only 3 of the 64 lanes need.
-// Here lane (slot, r) holds robot r of env `slot`: the same per-robot instruction stream now advances 16 (or 8) envs,
-// per-env "scalars" are replicated across the G lanes of a group, and the list-shaped work (static-rect collisions,
-// green-zone window, closest trajectory point) is strided over the G lanes of the group with group-local reductions.
-// Cross-lane traffic never leaves a group and is only issued where all lanes of the group are active (loops have
-// group-uniform trip counts, r-dependent branches contain no shuffles), so env-level divergence between groups is safe.
+// Lane (slot, r) holds robot r of env `slot` (0 leader, 1 follower, 2.. bears): the per-robot instruction stream (controller, f64
+// sin/cos integrator, integer hitbox, steering) advances 16 (or 8) envs at once, per-env "scalars" are replicated across the G lanes
+// of a group, and the list-shaped work (static-rect collisions, green-zone window, closest trajectory point, tracker sums) is strided
+// over the G lanes of the group with group-local reductions (DPP quad_perm moves for G = 4).  Cross-lane traffic never leaves a group
+// and is only issued where all lanes of the group are active (loops have group-uniform trip counts, r-dependent branches contain no
+// shuffles), so env-level divergence between groups is safe.  (A one-wavefront-per-env version of this kernel was the round's first
+// correct path -- 8.4 M env-steps/s, profiles/r01_a_* -- and is gone.)
 //
-// Semantics are those of ftl_frames_kernel / oracle/ftl_oracle.c operation by operation; reference citations as there.
+// Semantics are those of oracle/ftl_oracle.c operation by operation; reference citations as there.
 #pragma once
 #include "ftl_device.hpp"
 
