@@ -5,7 +5,7 @@ against ``ftl_sizeof_*`` exported by the library."""
 import ctypes as C
 
 FTL_ABI_VERSION = 2
-FTL_MAX_BEARS = 4
+FTL_MAX_BEARS = 6
 FTL_MAX_LASERS = 4
 FTL_MAX_AUX = 8
 AUX_LIDAR, AUX_TRACK_VECTOR, AUX_TRACK_RADAR = 1, 2, 3
@@ -28,9 +28,9 @@ FTL_METRICS_CLEAR = 1
 # env_int indices
 (EI_SCEN, EI_TARGET_ID, EI_LEADER_FINISHED, EI_DONE, EI_CRASH, EI_IN_BOX, EI_ON_TRACE, EI_TOO_CLOSE,
  EI_STEP_COUNT, EI_FINISH_TIMER, EI_TRAJ_LEN, EI_TRK_COUNTER, EI_CORR_LO, EI_CORR_HI, EI_SEED_END,
- EI_SNAP_COUNT, EI_DYN_INDEX0, EI_DYN_INDEX1, EI_DYN_INDEX2, EI_DYN_INDEX3, EI_ERROR, EI_EPISODES,
+ EI_SNAP_COUNT, EI_DYN_INDEX0, EI_DYN_INDEX1, EI_DYN_INDEX2, EI_DYN_INDEX3, EI_DYN_INDEX4, EI_DYN_INDEX5, EI_ERROR, EI_EPISODES,
  EI_GREEN_COUNT, EI_GREEN_LEN, EI_SCAN_OK, EI_SNAP_HEAD, EI_HINT, EI_GREEN_TINY, EI_RESETS, EI_ACC_CONSUMED,
- EI_HINT_X, EI_HINT_Y, EI_CLR_GREEN, EI_CLR_ALL, EI_FPS, EI_HW0_LO, EI_HW0_HI, EI_HIST1_LEN, EI_ERROR_STICKY, EI_COUNT) = range(40)
+ EI_HINT_X, EI_HINT_Y, EI_CLR_GREEN, EI_CLR_ALL, EI_FPS, EI_HW0_LO, EI_HW0_HI, EI_HIST1_LEN, EI_ERROR_STICKY, EI_COUNT) = range(42)
 ED_ACC_PENALTY, ED_OVERALL_REWARD, ED_SPARE0, ED_SPARE1, ED_BEAR_POINTS = range(5)
 ED_GREEN_W = ED_BEAR_POINTS + 2 * FTL_MAX_BEARS
 ED_CUR_MULT, ED_CUR_ACC, ED_CUM_SPEED = ED_GREEN_W + 1, ED_GREEN_W + 2, ED_GREEN_W + 3
@@ -43,6 +43,13 @@ def rand_frames(rng_seed, env_id, resets, step_count, lo, hi):
     """Twin of ftl_rand_frames (include/ftl.h): the stand-in for np.random.randint(lo, hi) at ENV:405/940."""
     v = lo + int(uniform01(rng_seed, env_id, resets, step_count | (1 << 40)) * (hi - lo))
     return v if v < hi else hi - 1
+
+
+def rand_range(rng_seed, env_id, resets, frame, bear, k, start, stop):
+    """Twin of ftl_rand_range (include/ftl.h): the stand-in for random.randrange(start, stop, 10) at ENV:753-754."""
+    n = (stop - start + 9) // 10
+    v = int(uniform01(rng_seed, env_id, resets, frame | (1 << 41) | (bear << 44) | (k << 48)) * n)
+    return start + 10 * (v if v < n else n - 1)
 
 
 class RobotParams(C.Structure):

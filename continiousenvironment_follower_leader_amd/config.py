@@ -179,7 +179,9 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
     if simulation_time_limit is not None:
         raise NotImplementedError("simulation_time_limit depends on the wall clock (ENV:1119-1123)")
     if add_bear and bear_number > abi.FTL_MAX_BEARS:
-        raise NotImplementedError("bears with index >= 4 draw from `random` inside step (ENV:750-754)")
+        raise NotImplementedError("at most %d bears (2 + bears robots share the 8 lanes of an env's group)" % abi.FTL_MAX_BEARS)
+    if add_bear and bear_number > 5 and move_bear_v4 and (max_distance * pixels_to_meter) != int(max_distance * pixels_to_meter):
+        raise ValueError("non-integer arg 1 for randrange()")      # ENV:753: random.randrange(self.max_distance, ..) with a fractional float
 
     def to_px(m):  # ENV:1942-1943
         return m * pixels_to_meter

@@ -488,9 +488,11 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         const int b = r - 2;
         bool near = euclid_f64_lt((double)E.rb.px, (double)E.rb.py, E.rb.tgt_x, E.rb.tgt_y, c.leader_pos_epsilon);
         double off, lvl;
+        bool drawn = false;
         if (c.move_bear_v4 && (b & 1)) {
             if (near) E.rb.dyn_index += 1;
             if (E.rb.dyn_index > 3) E.rb.dyn_index = 0;
+            drawn = b >= 4;       // ENV:750-754: bears 5, 7, .. take one of four points drawn anew every frame (ftl_rand_range, include/ftl.h)
             const int order = (b == 1) ? 0x2134 /*p4,p3,p1,p2*/ : 0x4213 /*p3,p1,p2,p4*/;
             int p = (order >> (4 * E.rb.dyn_index)) & 0xf;
             lvl = (p <= 2) ? 150.0 : 250.0;
@@ -503,6 +505,17 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         double s, co;
         sincos_bounded((ldir0 + off) * kDeg2Rad, s, co);
         tx = (double)lpx0 + co * lvl; ty = (double)lpy0 + s * lvl;
+        if (FTL_MAX_BEARS > 4 && drawn) {
+            const int lo = (int)c.max_distance, k = 2 * E.rb.dyn_index;
+            auto draw = [&](int kk, int stop) {
+                const int nn = (stop - lo + 9) / 10;
+                const double u = d_uniform01(c.rng_seed, (unsigned long long)(c.env_id_base + E.env), (unsigned long long)E.resets,
+                                             (unsigned long long)E.step_count | (1ULL << 41) | ((unsigned long long)b << 44) | ((unsigned long long)kk << 48));
+                const int v = (int)(u * (double)nn);
+                return (double)(lo + 10 * (v < nn ? v : nn - 1));
+            };
+            tx = draw(k, c.width - lo); ty = draw(k + 1, c.height - lo);
+        }
         E.rb.tgt_x = tx; E.rb.tgt_y = ty;
     }
     // leader speed / acceleration regimes (ENV:1048-1058, 1143-1174); evaluated only while the leader is under way

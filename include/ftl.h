@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 #define FTL_ABI_VERSION 2
-#define FTL_MAX_BEARS 4   /* bears with index >= 4 draw from `random` inside step (ENV:750-754): unsupported */
+#define FTL_MAX_BEARS 6   /* robots per env = 2 + bears <= 8 (one lane each in a group of the frame kernel); bears 5, 7, .. of
+                             move_bear_v4 draw their way-points from `random` every frame (ENV:750-754): ftl_rand_range below */
 #define FTL_MAX_LASERS 4
 #define FTL_MAX_AUX 8     /* lidar / leader-track detectors per env (ftl_aux_cfg) */
 #define FTL_MAX_REGIME 16 /* entries of leader_speed_regime / leader_acceleration_regime */
@@ -183,6 +184,17 @@ static inline int32_t ftl_rand_frames(uint64_t rng_seed, uint64_t env_id, uint64
     return v < hi ? v : hi - 1;
 }
 
+/* random.randrange(start, stop, 10) of ENV:753-754 (the way-points of bears with an odd index >= 5 under move_bear_v4: four (x, y)
+ * pairs per bear and frame, of which the pair at dynamics_index is used) on the same counter stream, key range bit 41: draw `k`
+ * (0..7 = x, y of pair 0..3) of bear `bear` in frame `frame`.  CPython: start + 10 * _randbelow(ceil((stop - start) / 10)). */
+static inline int32_t ftl_rand_range(uint64_t rng_seed, uint64_t env_id, uint64_t resets, uint64_t frame, int32_t bear, int32_t k,
+                                     int32_t start, int32_t stop) {
+    const int32_t n = (stop - start + 9) / 10;
+    double u = ftl_uniform01(rng_seed, env_id, resets, frame | (1ULL << 41) | ((uint64_t)bear << 44) | ((uint64_t)k << 48));
+    int32_t v = (int32_t)(u * (double)n);
+    return start + 10 * (v < n ? v : n - 1);
+}
+
 /* Scenario pool = output of the reference's reset() (ENV:434-543) for P episodes, device arrays.
  * Robots are ordered leader, follower, bear0.. (R = 2 + n_bears). */
 typedef struct ftl_scenarios {
@@ -324,7 +336,7 @@ enum {
     FTL_EI_SCEN = 0, FTL_EI_TARGET_ID, FTL_EI_LEADER_FINISHED, FTL_EI_DONE, FTL_EI_CRASH, FTL_EI_IN_BOX,
     FTL_EI_ON_TRACE, FTL_EI_TOO_CLOSE, FTL_EI_STEP_COUNT, FTL_EI_FINISH_TIMER, FTL_EI_TRAJ_LEN,
     FTL_EI_TRK_COUNTER, FTL_EI_CORR_LO, FTL_EI_CORR_HI, FTL_EI_SEED_END, FTL_EI_SNAP_COUNT,
-    FTL_EI_DYN_INDEX0, FTL_EI_DYN_INDEX1, FTL_EI_DYN_INDEX2, FTL_EI_DYN_INDEX3,
+    FTL_EI_DYN_INDEX0, FTL_EI_DYN_INDEX1, FTL_EI_DYN_INDEX2, FTL_EI_DYN_INDEX3, FTL_EI_DYN_INDEX4, FTL_EI_DYN_INDEX5,
     FTL_EI_ERROR, FTL_EI_EPISODES, FTL_EI_GREEN_COUNT, FTL_EI_GREEN_LEN,
     FTL_EI_SCAN_OK,   /* bit g set: the ray sensors of dict-order group g (before / after the tracker's 2nd scan) scanned this step */
     FTL_EI_SNAP_HEAD, /* ring slot the next snapshot goes to (= snap_count mod max_prev_obs, kept incrementally) */

@@ -314,6 +314,13 @@ static void move_bear_v4(ftlo_env* e, int idx, double* ox, double* oy) {
     if (euclid_f64((double)b->px, (double)b->py, e->bear_pt[idx][0], e->bear_pt[idx][1]) < e->cfg.leader_pos_epsilon)
         e->dyn_index[idx] += 1;
     if (e->dyn_index[idx] > 3) e->dyn_index[idx] = 0;
+    if (idx >= 4) {   /* ENV:750-754: four random points per frame, the one at dynamics_index is used; random.randrange -> ftl_rand_range */
+        const ftl_config* c = &e->cfg;
+        const int lo = (int)c->max_distance, k = 2 * e->dyn_index[idx];
+        *ox = (double)ftl_rand_range(c->rng_seed, (uint64_t)c->env_id_base, e->resets, (uint64_t)e->step_count, idx, k, lo, c->width - lo);
+        *oy = (double)ftl_rand_range(c->rng_seed, (uint64_t)c->env_id_base, e->resets, (uint64_t)e->step_count, idx, k + 1, lo, c->height - lo);
+        return;
+    }
     /* p1=(150,+140) p2=(150,-140) p3=(250,-160) p4=(250,+160) */
     static const int order[4][4] = { {1, 2, 4, 3}, {4, 3, 1, 2}, {2, 4, 3, 1}, {3, 1, 2, 4} };
     int p = order[idx][e->dyn_index[idx]];

@@ -109,7 +109,7 @@ class OracleEnv:
         dbl = np.zeros((self.R, 5), np.float64)
         ints = np.zeros((self.R, 6), np.int32)
         self.lib.ftlo_get_robots(self.h, _p(pos), _p(dbl), _p(ints))
-        cnt = np.zeros(19, np.int64)
+        cnt = np.zeros(15 + abi.FTL_MAX_BEARS, np.int64)
         acc = np.zeros(2, np.float64)
         self.lib.ftlo_get_counters(self.h, _p(cnt), _p(acc))
         cap = self.cfg.c.corr_cap

@@ -135,6 +135,8 @@ CONFIGS = {
                                    "back_lasers_count": 2, "laser_length": 90})])), post=None),
     # three bears (odd index -> _move_bear_v4), sensors of B
     "B3": dict(kwargs=dict(bear_number=3, follower_sensors=SENSORS_B), post=None),
+    # six bears: index 4 snakes at radius 500, index 5 chases four way-points drawn anew every frame (ENV:750-754)
+    "B6": dict(kwargs=dict(bear_number=6, follower_sensors=SENSORS_B), post=None),
     # config C: B's tracker + Prev sensor + two LeaderCorridor_lasers_compas (SEN:1138-1288), one scanned before the tracker's second
     # scan of the step and one after it
     "C": dict(kwargs=dict(bear_number=1, follower_sensors=OrderedDict([
@@ -211,9 +213,28 @@ class Runner:
         self.frame = 0
         orig = self.game.frame_step
 
+        # bears with an odd index >= 5 draw four way-points per frame with random.randrange (ENV:750-754); the
+        # draws are replaced by the build's counter stream (include/ftl.h ftl_rand_range) for the duration of a frame only -- reset()
+        # keeps CPython's own randrange for the rocks
+        import random as _rnd
+        from continiousenvironment_follower_leader_amd.abi import rand_range
+        qual = [b for b in range(self.game.bear_number if self.game.add_bear else 0) if b % 2 and b >= 4]
+
         def frame_step(action):
             self.frame += 1
-            return orig(action)
+            calls = [0]
+
+            def randrange(start, stop, step=1):
+                assert step == 10 and qual, (start, stop, step)
+                k = calls[0]
+                calls[0] += 1
+                return rand_range(0, 0, self.resets, self.game.step_count, qual[k // 8], k % 8, int(start), int(stop))
+            real = _rnd.randrange
+            _rnd.randrange = randrange
+            try:
+                return orig(action)
+            finally:
+                _rnd.randrange = real
 
         self.game.frame_step = frame_step
         self.pygame.time._ticks_fn = lambda: self.frame
@@ -467,6 +488,8 @@ EPISODES = [
     ("Bes_s2_random", "B_es", 2, "random", 200),
     ("Bes_s6_chase", "B_es", 6, "chase_noisy", 200),
     ("B3_s8_chase", "B3", 8, "chase", 250),
+    ("B6_s2_chase", "B6", 2, "chase", 250),
+    ("B6_s9_random", "B6", 9, "random", 120),
     ("D_s2_chase", "D", 2, "chase", 60),
     ("D_s7_random", "D", 7, "random", 60),
     ("M_s3_chase", "M", 3, "chase", 100),

@@ -52,7 +52,7 @@ class OracleBatch:
     def counters(self):
         """(step_count[n], overall_reward[n], error[n]) of every env."""
         sc = np.zeros(self.n, np.int64); ret = np.zeros(self.n); err = np.zeros(self.n, np.int64)
-        cnt = np.zeros(19, np.int64); acc = np.zeros(2)
+        cnt = np.zeros(32, np.int64); acc = np.zeros(2)
         for e, o in enumerate(self.envs):
             self.lib.ftlo_get_counters(o.h, cnt.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p))
             sc[e] = cnt[0]; ret[e] = acc[1]; err[e] = cnt[14]

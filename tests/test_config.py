@@ -62,7 +62,7 @@ def test_sensor_registry_and_dict_order():
     (dict(follower_sensors={"c": {"sensor_class": "LeaderCorridor_lasers_compas", "max_prev_obs": 5}}), ValueError),   # SEN:1148-1151: flags
     (dict(follower_sensors={"c": {"sensor_class": "LeaderCorridor_Prev_lasers_v3", "max_prev_obs": 5}}), ValueError),  # SEN:993
     (dict(manual_control=True), NotImplementedError),
-    (dict(bear_number=5), NotImplementedError),
+    (dict(bear_number=7), NotImplementedError),
 ])
 def test_constructor_errors(kw, exc):
     with pytest.raises(exc):

@@ -42,7 +42,8 @@ def test_hip_matches_reference_episode(name):
     torch.cuda.synchronize()
     lnames = meta["laser_names"]
     # a random speed regime draws from the per-env counter stream (env id in the key): only env 0 replays the episode
-    rnd = any(cfg.c.speed_is_range[i] for i in range(max(cfg.c.n_speed_regime, 0))) or cfg.c.rand_fps_hi > 0
+    rnd = any(cfg.c.speed_is_range[i] for i in range(max(cfg.c.n_speed_regime, 0))) or cfg.c.rand_fps_hi > 0 \
+        or (cfg.c.n_bears > 5 and cfg.c.move_bear_v4)          # bear 5's way-points come from the per-env stream too (ENV:750-754)
     envs = [0] if rnd else list(range(n))
     last = envs[-1]
 
