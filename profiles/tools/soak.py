@@ -24,13 +24,14 @@ def run(name, cfg, pool_fn, n, steps):
         st_hist += torch.bincount(env.status[:, 1][d].to(torch.int64), minlength=8)[:8]
         if k % 500 == 499:
             ei = env.state_field("env_int")
-            err = int((ei[:, abi.EI_ERROR] != 0).sum().item())
+            err = env.error_report()[0]      # sticky words: errors of episodes that auto-reset wiped count too
             fin = bool(torch.isfinite(env.obs_num).all().item()) and bool(torch.isfinite(env.lasers).all().item())
             print("%s step %5d: error envs %d, finite %s, episodes %.0f, agent-status histogram of finished episodes %s, max traj_len %d" % (
                 name, k + 1, err, fin, done_sum.item(), st_hist.cpu().numpy().astype(int).tolist(), int(ei[:, abi.EI_TRAJ_LEN].max().item())), flush=True)
             assert err == 0 and fin
     torch.cuda.synchronize()
-    print("%s: %d steps x %d envs in %.1f s" % (name, steps, n, time.time() - t))
+    print("%s: %d steps x %d envs in %.1f s; episode metrics %s" % (name, steps, n, time.time() - t, env.episode_metrics().tolist()))
+    assert abs(float(env.episode_metrics()[0]) - done_sum.item()) < 0.5
     w, h = cfg.c.width, cfg.c.height
     o = env.obs_num
     assert float(o[:, [0, 1, 5, 6]].min()) > -60 and float(o[:, [0, 5]].max()) < w + 60 and float(o[:, [1, 6]].max()) < h + 60
