@@ -6,6 +6,7 @@ python3 bench.py > gpurun_out/${TAG}_bench.log 2>&1 && tail -1 gpurun_out/${TAG}
 for w in D E F; do python3 bench.py --workload $w --steps 200 > gpurun_out/${TAG}_bench_$w.log 2>&1 && tail -1 gpurun_out/${TAG}_bench_$w.log > gpurun_out/${TAG}_bench_$w.json; done
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- python3 bench.py --no-cpu-baseline --kernel-steps 0 > gpurun_out/${TAG}_stats.log 2>&1
 cp gpurun_out/${TAG}_stats/*/*kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv
+python3 profiles/tools/stats_timed.py gpurun_out/${TAG}_stats/*/*kernel_trace.csv 400 > gpurun_out/${TAG}_kernel_stats_timed.csv   # the 400 timed steps only
 for w in D E; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats_$w -- python3 bench.py --workload $w --steps 200 --no-cpu-baseline --kernel-steps 0 > gpurun_out/${TAG}_stats_$w.log 2>&1
   cp gpurun_out/${TAG}_stats_$w/*/*kernel_stats.csv gpurun_out/${TAG}_kernel_stats_$w.csv
