@@ -38,7 +38,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-DEFAULT_ENVS = {"B": 65536, "D": 4096, "E": 32768, "F": 65536}
+DEFAULT_ENVS = {"B": 65536, "D": 4096, "E": 32768, "F": 65536, "C": 65536, "L": 65536, "T": 65536}
 
 
 def bytes_per_env_step(cfg, G, Cn):
@@ -112,7 +112,7 @@ def build_workload(name, n, rank, seed, device):
                 "(12 rays all edges L=100, 24 rays obstacles L=150, H=5), 10 frames/step, auto-reset from a %d-scenario pool "
                 "captured from the reference's reset()")
         return cfg, pool, text, 4096, ("ftl_frames_group_kernel<4, false>", "ftl_rays_kernel<5, false, false>")     # 4,010 B by the formula, the survey's rounded figure
-    ep = {"D": "D_s2_chase", "E": "E_s3_chase", "F": "F_s7_chase"}[name]
+    ep = {"D": "D_s2_chase", "E": "E_s3_chase", "F": "F_s7_chase", "C": "C_s1_chase", "L": "L_s2_chase", "T": "T_s3_chase"}[name]
     _, m = load_episode(ep)
     cfg = config_for(m, scen_route_len=256, env_id_base=base, rng_seed=seed)
     # the same seed list on every rank (env e of rank r starts from pool entry (seed*1000003 + r*n + e) mod P, shard.scenario_index)
@@ -126,6 +126,15 @@ def build_workload(name, n, rank, seed, device):
                 "5 frames/step, leader speed + acceleration regimes on per-env counter streams, early stopping, auto-reset from a %d-scenario "
                 "pool built by the host generator")
         return cfg, pool, text, bytes_per_env_step(cfg, 330, 103), ("ftl_frames_group_kernel<4, true>", "ftl_rays_kernel<5, false, false>")
+    if name in ("C", "L", "T"):
+        what = {"C": "tracker_v2 + Prev_lasers_v2 (12 rays) + two LeaderCorridor_lasers_compas (12 and 20 rays, H=5)",
+                "L": "tracker_v2 + two LaserSensor lidars (37 x 20 and 13 x 10 marching points) + three leader-track detectors + Prev_lasers_v2 (12 rays)",
+                "T": "the v1 LeaderPositionsTracker + LeaderCorridor_lasers + LeaderCorridor_lasers_v2 + two leader-track detectors"}[name]
+        text = "config " + name + " (row f3): %d envs/GPU, config B's world (" + ("2" if name == "L" else "1") + " dynamic obstacle) with " + what + \
+               ", 10 frames/step, auto-reset from a %d-scenario pool built by the host generator"
+        bpe = bytes_per_env_step(cfg, 161, 32) + 4 * sum(a.out_len for a in cfg.aux)
+        kn = ("ftl_frames_group_kernel<4, %s>" % ("false"), "ftl_rays_kernel<5, true, false> + ftl_aux_kernel" + (" + ftl_tracker1_kernel" if name == "T" else ""))
+        return cfg, pool, text, bpe, kn
     text = ("config F (server/config/3c1bc): %d envs/GPU, 20 rocks + 2 walls + 2 dynamic obstacles, same sensors with H=10, "
             "random 30-70 frames/step, random leader speed regimes, auto-reset from a %d-scenario pool built by the host generator")
     return cfg, pool, text, bytes_per_env_step(cfg, 330, 103), ("ftl_frames_group_kernel<4, true>", "ftl_rays_kernel<10, false, true>")
@@ -145,7 +154,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--kernel-steps", type=int, default=100, help="steps of the per-kernel HIP-event pass after the timed region")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--workload", default="B", choices=["B", "D", "E", "F"])
+    ap.add_argument("--workload", default="B", choices=["B", "D", "E", "F", "C", "L", "T"],
+                    help="B: the configuration the metric is quoted on.  D, E: the other BASELINE configs.  F: the shipped training config.  "
+                         "C, L, T (information only): config B's world with the row-f3 sensors -- compas ray sensors / lidars + leader-track "
+                         "detectors / the v1 tracker -- which add ftl_aux_kernel (and ftl_tracker1_kernel) to every step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the metrics all-reduce: nccl (= RCCL over xGMI, one GPU per rank) or gloo -- a rehearsal "
                          "of the N > 1 path on a box with fewer GPUs than ranks (every rank then uses GPU rank %% n_visible)")

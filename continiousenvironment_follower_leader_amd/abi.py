@@ -20,6 +20,7 @@ AGENT = ("moving", "crash", "low_reward", "too_far_from_leader", "finished")
 LEADER = ("moving", "crash", "finished")
 
 FTL_ERR_TRAJ_OVERFLOW, FTL_ERR_CORR_OVERFLOW, FTL_ERR_EMPTY_CORRIDOR, FTL_ERR_TRACKER_SEED, FTL_ERR_HIST1_OVERFLOW = 1, 2, 4, 8, 16
+FTL_ERR_LIDAR_OVERFLOW = 32
 FTL_STEP_AUTO_RESET = 1
 FTL_N_METRICS = 8
 FTL_METRICS_CLEAR = 1

@@ -371,7 +371,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
     {   // compas / lidar / leader-track detectors: one more launch, only for configs that have such a sensor
         bool aux = h->P.cfg.n_aux > 0;
         for (int k = 0; k < h->P.cfg.n_lasers; k++) aux = aux || h->P.cfg.lasers[k].compas != 0;
-        if (aux) hipLaunchKernelGGL(ftl_aux_kernel, dim3((unsigned)h->P.n_envs), dim3(FTL_WAVE), 0, (hipStream_t)stream, h->dP, call);
+        if (aux) hipLaunchKernelGGL(ftl_aux_kernel, dim3((unsigned)h->P.n_envs), dim3(FTL_WAVE), ftl_aux_lds_bytes(h->P.cfg), (hipStream_t)stream, h->dP, call);
     }
     // the frame kernel left every env's cost class for its next step: rebuild the slot -> env map.  The classes are stable
     // from step to step unless the frame count is random, so every second launch is enough then.

@@ -104,10 +104,12 @@ __device__ __forceinline__ bool wall_hit(double ax, double ay, double bx, double
 
 }  // namespace ftl
 
-// One wavefront per env.  LDS: [0, 16 KiB) scratch shared by the sensors, used one after the other.
+// One wavefront per env.  LDS: one scratch area shared by the sensors, used one after the other; its size is the largest any sensor of
+// the config needs (ftl_aux_lds_bytes below, passed at launch).
+#define FTL_LIDAR_RECTS 128          // objects in range of one lidar (more raise FTL_ERR_LIDAR_OVERFLOW and are ignored)
 __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     using namespace ftl;
-    __shared__ __align__(16) unsigned char lds[16384];
+    extern __shared__ __align__(16) unsigned char lds[];
     const FtlDevParams& P = *Pp;
     const ftl_config& c = P.cfg;
     const int env = blockIdx.x, lane = threadIdx.x;
@@ -164,9 +166,9 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
         for (int a = 0; a < nsnap; a++) { umin = min(umin, s_win[2 * a]); umax = max(umax, s_win[2 * a + 1]); }
         const int n_wall = nsnap > 0 ? 2 * max(umax - umin - 1, 0) : 0;
         const int n_items = n_wall + 2 * nsnap;
-        // (item, ray) pairs; an item is a wall shared by every snapshot whose window holds both of its points, or an end cap of ONE snapshot
-        for (int w = lane; w < n_items * N; w += FTL_WAVE) {
-            const int item = w / N, ray = w - item * N;
+        // one item per lane -- a wall shared by every snapshot whose window holds both of its points, or an end cap of ONE snapshot --
+        // against every ray in turn (the wall stays in registers; N <= 36)
+        for (int item = lane; item < n_items; item += FTL_WAVE) {
             double ax, ay, bx, by; unsigned sm = 0; int cls;
             if (item < n_wall) {
                 const int p = umin + (item >> 1), side = item & 1;             // side 0: right wall (class 3), 1: left wall (class 2)
@@ -181,13 +183,23 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
                 sm = 1u << a; cls = back;
             }
             if (!sm) continue;
-            const double2 e = s_ray[ray];
-            double d2;
-            if (wall_hit(ax, ay, bx, by, cx, cy, e.x, e.y, d2)) {
-                // np.argmin takes the FIRST of equal minima in the order front, back, left walls, right walls (SEN:1166): the class code
-                // rides in the two low mantissa bits, so equal distances resolve the same way (3 ulp of float64 before the float32 store)
-                const unsigned long long key = ((unsigned long long)__double_as_longlong(d2) & ~3ull) | (unsigned long long)cls;
-                for (int a = 0; a < nsnap; a++) if ((sm >> a) & 1u) atomicMin(&s_best[ray * H + a], key);
+            // a wall farther than the rays reach cannot be hit (2 px of slack)
+            {
+                const double ux = bx - ax, uy = by - ay, l2 = ux * ux + uy * uy;
+                double t = l2 > 0.0 ? -((ax - cx) * ux + (ay - cy) * uy) / l2 : 0.0;
+                t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+                const double nx = ax + t * ux - cx, ny = ay + t * uy - cy, reach = Lc.length + 2.0;
+                if (nx * nx + ny * ny > reach * reach) continue;
+            }
+            for (int ray = 0; ray < N; ray++) {
+                const double2 e = s_ray[ray];
+                double d2;
+                if (wall_hit(ax, ay, bx, by, cx, cy, e.x, e.y, d2)) {
+                    // np.argmin takes the FIRST of equal minima in the order front, back, left walls, right walls (SEN:1166): the class code
+                    // rides in the two low mantissa bits, so equal distances resolve the same way (3 ulp of float64 before the float32 store)
+                    const unsigned long long key = ((unsigned long long)__double_as_longlong(d2) & ~3ull) | (unsigned long long)cls;
+                    for (int a = 0; a < nsnap; a++) if ((sm >> a) & 1u) atomicMin(&s_best[ray * H + a], key);
+                }
             }
         }
         __syncthreads();
@@ -214,10 +226,11 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
         float* out = out_base + A.out_offset;
         __syncthreads();
         if (A.kind == FTL_AUX_LIDAR) {
-            int4* s_rect = reinterpret_cast<int4*>(lds);                          // [<= 256] rects in range
-            float2* s_end = reinterpret_cast<float2*>(lds + 4096);                // [n_angles] ray ends
-            int* s_first = reinterpret_cast<int*>(lds + 4096 + 8 * 512);          // [n_angles] first marching point inside a rect
-            int* s_cnt = reinterpret_cast<int*>(lds + 4096 + 12 * 512);
+            const int n_ang = A.n_angles;
+            int4* s_rect = reinterpret_cast<int4*>(lds);                                          // [FTL_LIDAR_RECTS] rects in range
+            float2* s_end = reinterpret_cast<float2*>(lds + 16 * FTL_LIDAR_RECTS);                // [n_angles] ray ends
+            int* s_first = reinterpret_cast<int*>(lds + 16 * FTL_LIDAR_RECTS + 8 * n_ang);        // [n_angles] first marching point inside a rect
+            int* s_cnt = s_first + n_ang;
             if (lane == 0) *s_cnt = 0;
             __syncthreads();
             // objects_in_range (SEN:72-79): leader, static rects, bears whose nearest corner / edge mid-point is within range + 3 m
@@ -233,9 +246,8 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
                 double dmin = 1.0e300;
 #pragma unroll
                 for (int t = 0; t < 8; t++) dmin = fmin(dmin, euclid_f64(cx, cy, (double)px[t], (double)py[t]));
-                if (dmin <= A.in_range_px) { const int at = atomicAdd(s_cnt, 1); if (at < 256) s_rect[at] = q; }
+                if (dmin <= A.in_range_px) { const int at = atomicAdd(s_cnt, 1); if (at < FTL_LIDAR_RECTS) s_rect[at] = q; }
             }
-            const int n_ang = A.n_angles < 512 ? A.n_angles : 512;
             for (int a = lane; a < n_ang; a += FTL_WAVE) {                         // SEN:88-104
                 double angle = -fdir;
                 if (a > 0) { const double kk = (double)((a + 1) / 2) * A.angle_step; angle = angle_correction((a & 1) ? -fdir + kk : -fdir - kk); }
@@ -245,7 +257,11 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
                 s_first[a] = 0x7fffffff;
             }
             __syncthreads();
-            const int nin = min(*s_cnt, 256);
+            if (lane == 0 && *s_cnt > FTL_LIDAR_RECTS) {
+                int* eiw = P.env_int + (size_t)env * FTL_EI_COUNT;
+                atomicOr(&eiw[FTL_EI_ERROR], (int)FTL_ERR_LIDAR_OVERFLOW); atomicOr(&eiw[FTL_EI_ERROR_STICKY], (int)FTL_ERR_LIDAR_OVERFLOW);
+            }
+            const int nin = min(*s_cnt, FTL_LIDAR_RECTS);
             for (int w = lane; w < n_ang * A.points_number; w += FTL_WAVE) {       // SEN:106-121
                 const int a = w / A.points_number, i = w - a * A.points_number;
                 const double u = (double)i / (double)A.points_number;
@@ -294,7 +310,7 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
                 }
             } else {                                                               // SEN:423-476
                 unsigned* s_rad = reinterpret_cast<unsigned*>(lds);                // [sectors] float bits of the nearest distance (0x7f800000: none)
-                const int S = A.radar_sectors < 4096 ? A.radar_sectors : 4096;
+                const int S = A.radar_sectors;
                 for (int s = lane; s < S; s += FTL_WAVE) s_rad[s] = 0x7f800000u;
                 __syncthreads();
                 double sd, cd, sr, cr;
@@ -322,4 +338,19 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
             }
         }
     }
+}
+
+// dynamic LDS of ftl_aux_kernel for a config
+static inline size_t ftl_aux_lds_bytes(const ftl_config& c) {
+    size_t need = 64;
+    for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].compas) {
+        const size_t b = (size_t)c.lasers[k].count * 16 + (size_t)c.lasers[k].count * c.lasers[k].history * 8 + (size_t)c.lasers[k].history * 8;
+        need = b > need ? b : need;
+    }
+    for (int j = 0; j < c.n_aux; j++) {
+        const ftl_aux_cfg& a = c.aux[j];
+        const size_t b = a.kind == FTL_AUX_LIDAR ? (size_t)16 * FTL_LIDAR_RECTS + (size_t)12 * a.n_angles + 16 : a.kind == FTL_AUX_TRACK_RADAR ? (size_t)4 * a.radar_sectors : 0;
+        need = b > need ? b : need;
+    }
+    return (need + 15) & ~(size_t)15;
 }

@@ -93,7 +93,8 @@ def error_for_bits(bits, n_envs=1):
     if bits & abi.FTL_ERR_EMPTY_CORRIDOR:       # SEN:893/962: `all_obs_arr` is unbound when len(corridor) <= 1
         return UnboundLocalError("local variable 'all_obs_arr' referenced before assignment (ray sensor scanned with a "
                                  "corridor of <= 1 points, sensors.py:893-962; %s)" % where)
-    names = [n for b, n in ((abi.FTL_ERR_TRAJ_OVERFLOW, "traj_cap"), (abi.FTL_ERR_CORR_OVERFLOW, "corr_cap")) if bits & b]
+    names = [n for b, n in ((abi.FTL_ERR_TRAJ_OVERFLOW, "traj_cap"), (abi.FTL_ERR_CORR_OVERFLOW, "corr_cap"), (abi.FTL_ERR_HIST1_OVERFLOW, "hist1_cap"),
+                            (abi.FTL_ERR_LIDAR_OVERFLOW, "objects within a lidar's range")) if bits & b]
     return _lib.FtlError("capacity overflow of the batched state (%s) in %s: results after the overflow differ from the "
                          "reference -- raise the capacity in make_config()" % (", ".join(names) or hex(bits), where))
 
@@ -220,7 +221,8 @@ class VecGame:
 
     def kernel_times(self):
         """Average per-kernel duration in microseconds over the steps timed since the last call:
-        ``dict(frames_us, rays_us, regroup_us, steps)`` (regroup = both regroup kernels, averaged over ALL steps)."""
+        ``dict(frames_us, rays_us, regroup_us, steps)`` (frames includes the v1 tracker's kernel when the config has one; regroup =
+        everything after the ray kernel: ftl_aux_kernel for configs with row-f3 sensors + both regroup kernels, averaged over ALL steps)."""
         ms, n = (C.c_double * 3)(), C.c_int32()
         _lib.check(self.lib.ftl_kernel_times(self.h, C.byref(ms), C.byref(n)), self.lib)
         k = max(n.value, 1)

@@ -56,6 +56,7 @@ enum { FTL_LEADER_MOVING = 0, FTL_LEADER_CRASH = 1, FTL_LEADER_FINISHED = 2 };
 #define FTL_ERR_EMPTY_CORRIDOR 4u     /* SEN:893/962: scan with len(corridor) <= 1 (reference: UnboundLocalError) */
 #define FTL_ERR_TRACKER_SEED 8u       /* SEN:264-297: fewer than 2 seed points / popleft on empty corridor */
 #define FTL_ERR_HIST1_OVERFLOW 16u    /* v1 tracker history longer than hist1_cap */
+#define FTL_ERR_LIDAR_OVERFLOW 32u    /* more than 128 objects within range of a LaserSensor: the extra ones were ignored */
 
 /* robot kinematic limits, px/frame and deg/frame (ENV:330-357, 556-566, 704-714; CLS:59-105) */
 typedef struct ftl_robot_params {
