@@ -133,7 +133,7 @@ class ScenParams(C.Structure):
                 ("add_obstacles", C.c_int32), ("add_bear", C.c_int32), ("bear_number", C.c_int32), ("bear_behind", C.c_int32),
                 ("multiple_end_points", C.c_int32), ("path_finding_iterations", C.c_int32),
                 ("bridge_gap", C.c_int32), ("bridge_width", C.c_int32),
-                ("trajectory_saving_period", C.c_int32), ("_pad", C.c_int32),
+                ("trajectory_saving_period", C.c_int32), ("planner", C.c_int32),
                 ("min_distance", C.c_double), ("max_distance", C.c_double),
                 ("leader_pos_epsilon", C.c_double), ("leader_margin", C.c_double),
                 ("leader_w", C.c_double), ("leader_h", C.c_double), ("leader_max_speed", C.c_double)]

@@ -169,6 +169,73 @@ bool plan_route(const Grid& g, int sx, int sy, int gx, int gy, int max_iterat, s
     return true;
 }
 
+// ---- utils/astar.py:50-166, literally: nodes ordered by f = g + h with h = SQUARED distance to the goal, CPython heapq (ties keep the
+// heap's own order), a closed LIST, duplicates in the open list unless an open node at the same cell has a smaller g, and a cap of
+// 1000 expansions after which the path to the LAST expanded node is returned (return_none_on_max_iter=False, ENV:1681-1695).
+// Returns false when the open list runs dry (the reference returns None).  Path cells are appended to px / py in grid units.
+struct ANode { int x, y, g, f, parent; };
+bool astar_route(const std::vector<uint8_t>& maze, int gw, int gh, int sx, int sy, int ex, int ey, int max_iterations,
+                 std::vector<int>& px, std::vector<int>& py) {
+    std::vector<ANode> nodes;                       // every node ever created (parent = index)
+    std::vector<int> heap;                          // open_list as CPython's heapq keeps it (indices into nodes)
+    std::vector<int> closed;                        // closed_list (indices), membership by position
+    std::vector<uint8_t> in_closed((size_t)gw * gh, 0);
+    auto lt = [&](int a, int b) { return nodes[(size_t)a].f < nodes[(size_t)b].f; };
+    auto siftdown = [&](int startpos, int pos) {
+        const int item = heap[(size_t)pos];
+        while (pos > startpos) {
+            const int pp = (pos - 1) >> 1;
+            if (lt(item, heap[(size_t)pp])) { heap[(size_t)pos] = heap[(size_t)pp]; pos = pp; continue; }
+            break;
+        }
+        heap[(size_t)pos] = item;
+    };
+    auto siftup = [&](int pos) {
+        const int endpos = (int)heap.size(), startpos = pos, item = heap[(size_t)pos];
+        int child = 2 * pos + 1;
+        while (child < endpos) {
+            const int right = child + 1;
+            if (right < endpos && !lt(heap[(size_t)child], heap[(size_t)right])) child = right;
+            heap[(size_t)pos] = heap[(size_t)child]; pos = child; child = 2 * pos + 1;
+        }
+        heap[(size_t)pos] = item;
+        siftdown(startpos, pos);
+    };
+    auto push = [&](int n) { heap.push_back(n); siftdown(0, (int)heap.size() - 1); };
+    auto pop = [&]() { const int last = heap.back(); heap.pop_back(); if (heap.empty()) return last; const int ret = heap[0]; heap[0] = last; siftup(0); return ret; };
+    auto emit = [&](int n) {                       // return_path: goal-to-start chain, reversed
+        std::vector<int> chain;
+        for (int c = n; c >= 0; c = nodes[(size_t)c].parent) chain.push_back(c);
+        for (size_t i = chain.size(); i-- > 0;) { px.push_back(nodes[(size_t)chain[i]].x); py.push_back(nodes[(size_t)chain[i]].y); }
+    };
+    nodes.push_back(ANode{sx, sy, 0, 0, -1});
+    push(0);
+    static const int dx8[8] = {0, 0, -1, 1, -1, -1, 1, 1}, dy8[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
+    int outer = 0, current = -1;
+    while (!heap.empty()) {
+        outer++;
+        if (outer > max_iterations) { emit(current); return true; }       // "giving up on pathfinding too many iterations"
+        current = pop();
+        closed.push_back(current);
+        const ANode cur = nodes[(size_t)current];
+        if (cur.x >= 0 && cur.x < gw && cur.y >= 0 && cur.y < gh) in_closed[(size_t)cur.x * gh + cur.y] = 1;
+        if (cur.x == ex && cur.y == ey) { emit(current); return true; }
+        for (int d = 0; d < 8; d++) {
+            const int nx = cur.x + dx8[d], ny = cur.y + dy8[d];
+            if (nx > gw - 1 || nx < 0 || ny > gh - 1 || ny < 0) continue;
+            if (maze[(size_t)nx * gh + ny] != 0) continue;
+            if (in_closed[(size_t)nx * gh + ny]) continue;                  // child is on the closed list
+            const int g = cur.g + 1, h = (nx - ex) * (nx - ex) + (ny - ey) * (ny - ey);
+            bool worse = false;                                          // an open node at this cell with a smaller g
+            for (int o : heap) if (nodes[(size_t)o].x == nx && nodes[(size_t)o].y == ny && g > nodes[(size_t)o].g) { worse = true; break; }
+            if (worse) continue;
+            nodes.push_back(ANode{nx, ny, g, g + h, current});
+            push((int)nodes.size() - 1);
+        }
+    }
+    return false;                                                        // "Couldn't get a path to destination"
+}
+
 struct Obj { Rect r; float px, py; int w, h; };             // GameObject: rectangle, float32 start_position, height/width
 
 void generate_one(const ftl_config& c, const ftl_scen_params& sp, int64_t seed, int idx, const ftl_scenarios& out, uint8_t* status) {
@@ -250,10 +317,53 @@ void generate_one(const ftl_config& c, const ftl_scen_params& sp, int64_t seed, 
             else finish_point(20, (long)(H / 2.0), W - 20, H - 20, f3x, f3y);
         }
     }
-    // ---- generate_trajectory_dstar (ENV:1493-1612)
     std::vector<long> route_x, route_y;
     bool found = ok;
-    if (ok) {
+    if (ok && sp.planner == 1) {
+        // ---- generate_trajectory_astar (ENV:1632-1711): a 20 px grid, obstacles inflated by 2 x the leader's larger side, the bridge row
+        // cleared, one leg to the near end of the bridge and one from its far end to the finish point
+        const int a_sg = 20;
+        const int sx = (int)(lpx / (float)a_sg), sy = (int)(lpy / (float)a_sg);
+        const int ex = (int)((double)f1x / a_sg), ey = (int)((double)f1y / a_sg);
+        const int gw = (int)((double)W / a_sg), gh = (int)((double)H / a_sg);
+        std::vector<uint8_t> maze((size_t)gw * gh, 0);
+        const int lsf = (int)(fmax(sp.leader_w, sp.leader_h) * 2);
+        for (const Obj& o : objs) {
+            const int x0 = std::max((int)((double)(o.r.x - lsf) / a_sg), 0), x1 = std::min((int)((double)(o.r.right() + lsf) / a_sg), gw - 1);
+            const int y0 = std::max((int)((double)(o.r.y - lsf) / a_sg), 0), y1 = std::min((int)((double)(o.r.bottom() + lsf) / a_sg), gh - 1);
+            for (int x = x0; x < x1; x++) for (int y = y0; y < y1; y++) maze[(size_t)x * gh + y] = 1;
+        }
+        std::vector<int> px, py;
+        bool got = true;
+        if (sp.add_obstacles && objs.size() >= 2) {
+            const Obj& w1 = objs[0]; const Obj& w2 = objs[1];
+            // self.bridge_point: float32 mean of the two wall centres (ENV:636-637), / 20 in float32, truncated
+            const float bpx = (float)(((double)w1.px + (double)w2.px) / 2), bpy = (float)(((double)w1.py + (double)w2.py) / 2);
+            const int bx = (int)(bpx / (float)a_sg), by = (int)(bpy / (float)a_sg);
+            auto clear = [&](int x, int y) {              // numpy indexing: a negative index wraps around
+                if (x < 0) x += gw; if (y < 0) y += gh;
+                if (x >= 0 && x < gw && y >= 0 && y < gh) maze[(size_t)x * gh + y] = 0;
+            };
+            clear(bx, by);
+            for (int i = (int)(((double)w1.r.x / a_sg) - ((double)lsf / a_sg)); i < (int)(((double)w1.r.right() / a_sg) + ((double)lsf / a_sg)); i++) clear(i, by);
+            const int fbx = (int)(((double)w1.r.right() + sp.leader_pos_epsilon) / a_sg), sbx = (int)(((double)w1.r.x - sp.leader_pos_epsilon) / a_sg);
+            got = astar_route(maze, gw, gh, sx, sy, fbx, by, 1000, px, py);
+            if (got) {
+                for (size_t i = 0; i < px.size(); i++) { route_x.push_back((long)px[i] * a_sg); route_y.push_back((long)py[i] * a_sg); }
+                // `if path[-1] != first_bridge_point` compares a pixel pair with a grid pair (ENV:1684): they only coincide at the origin
+                if (!(route_x.back() == fbx && route_y.back() == by)) { route_x.push_back((long)((double)w1.r.right() + sp.leader_pos_epsilon)); route_y.push_back((long)a_sg * by); }
+                px.clear(); py.clear();
+                if (astar_route(maze, gw, gh, sbx, by, ex, ey, 1000, px, py))
+                    for (size_t i = 0; i < px.size(); i++) { route_x.push_back((long)px[i] * a_sg); route_y.push_back((long)py[i] * a_sg); }
+            }
+        } else {
+            got = astar_route(maze, gw, gh, sx, sy, ex, ey, 1000, px, py);
+            if (got) for (size_t i = 0; i < px.size(); i++) { route_x.push_back((long)px[i] * a_sg); route_y.push_back((long)py[i] * a_sg); }
+        }
+        found = route_x.size() >= 2;                  // the reference leaves found_target_point False (ENV:1537 is D*-only): "usable" = it can be stepped
+    }
+    // ---- generate_trajectory_dstar (ENV:1493-1612)
+    if (ok && sp.planner != 1) {
         Grid g; g.rows = W / sg; g.cols = H / sg; g.obst.assign((size_t)g.rows * g.cols, 0);
         const int margin = (int)floor(sp.leader_margin * fmax(sp.leader_w, sp.leader_h) / sg);
         // order of the reference: rocks, then the two walls (irrelevant for a set of cells)

@@ -17,8 +17,8 @@ USABLE_MASK = abi.SCEN_DONE_AT_RESET | abi.SCEN_ROUTE_OVERFLOW | abi.SCEN_TRAJ_O
 def scen_params(cfg: GameConfig) -> abi.ScenParams:
     """The generator's view of ``Game(**kwargs)`` (ENV:45-105, 283-357)."""
     kw, c = cfg.kwargs, cfg.c
-    if kw["path_finding_algorythm"] != "dstar":
-        raise NotImplementedError("the scenario generator implements the dstar planner (ENV:1493-1612) only")
+    if kw["path_finding_algorythm"] not in ("dstar", "astar"):
+        raise ValueError("path_finding_algorythm {} not in list:{}".format(kw["path_finding_algorythm"], ["astar", "dstar"]))
     if kw["trajectory"] is not None:
         raise NotImplementedError("a fixed `trajectory` needs no generated route; pass the scenario arrays yourself")
     ptm = cfg.pixels_to_meter
@@ -33,6 +33,7 @@ def scen_params(cfg: GameConfig) -> abi.ScenParams:
     sp.path_finding_iterations = int(kw["path_finding_iterations"])
     sp.bridge_gap, sp.bridge_width = int(kw["bridge_size"][0]), int(kw["bridge_size"][1])
     sp.trajectory_saving_period = c.trajectory_saving_period
+    sp.planner = 1 if kw["path_finding_algorythm"] == "astar" else 0
     sp.min_distance, sp.max_distance = c.min_distance, c.max_distance
     sp.leader_pos_epsilon, sp.leader_margin = float(kw["leader_pos_epsilon"]), float(kw["leader_margin"])
     sp.leader_w, sp.leader_h = kw["leader_size"][0] * ptm, kw["leader_size"][1] * ptm    # ENV:352-353

@@ -216,7 +216,10 @@ typedef struct ftl_scenarios {
  * finish point (ENV:1614-1630), grid route (ENV:1493-1612 on utils/dstar.py:84-210), bears (ENV:687-720, 761-770),
  * initial leader trajectory (ENV:533-539).  The draws come from a bit-compatible twin of CPython's `random`
  * (MT19937, seed(int), randrange) so that seed s yields the scenario of `game.seed(s); game.reset()`.
- * The route is a shortest 8-connected path on the reference's cost model (1 / sqrt 2 per move, inflated obstacle
+ * planner 1 ("astar") follows utils/astar.py:50-166 literally -- f = g + squared distance, CPython's heapq order on ties, the 1000-iteration
+ * cap that returns the path to the last expanded node, the two legs through the bridge (ENV:1670-1700); found_target_point stays False as
+ * in the reference (ENV:1537 is D*-only), so FTL_SCEN_FOUND is set whenever the route has at least two points.
+ * The (dstar) route is a shortest 8-connected path on the reference's cost model (1 / sqrt 2 per move, inflated obstacle
  * cells); among equal-cost paths the reference's choice depends on CPython set iteration order over object ids and is
  * not reproducible -- the generator breaks such ties by insertion order (documented as unpinned in DESIGN.md). */
 typedef struct ftl_scen_params {
@@ -225,7 +228,8 @@ typedef struct ftl_scen_params {
     int32_t add_obstacles, add_bear, bear_number, bear_behind;
     int32_t multiple_end_points, path_finding_iterations;
     int32_t bridge_gap, bridge_width;     /* bridge_size[0], bridge_size[1] (ENV:617-620) */
-    int32_t trajectory_saving_period, _pad;
+    int32_t trajectory_saving_period;
+    int32_t planner;                      /* path_finding_algorythm: 0 "dstar" (ENV:1493-1612), 1 "astar" (ENV:1632-1711 on utils/astar.py) */
     double  min_distance, max_distance;   /* pixels */
     double  leader_pos_epsilon, leader_margin;
     double  leader_w, leader_h;           /* the float pixel sizes the reference keeps on the robot (ENV:352-353, CLS:104-105) */

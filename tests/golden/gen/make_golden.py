@@ -135,6 +135,9 @@ CONFIGS = {
                                    "back_lasers_count": 2, "laser_length": 90})])), post=None),
     # three bears (odd index -> _move_bear_v4), sensors of B
     "B3": dict(kwargs=dict(bear_number=3, follower_sensors=SENSORS_B), post=None),
+    # the A* planner variant of reset() (ENV:1632-1711 on utils/astar.py): greedy f = g + squared distance on a 20 px grid, two legs through
+    # the bridge, a 1000-expansion cap that returns the path to the last expanded node
+    "B_astar": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B, path_finding_algorythm="astar"), post=None),
     # six bears: index 4 snakes at radius 500, index 5 chases four way-points drawn anew every frame (ENV:750-754)
     "B6": dict(kwargs=dict(bear_number=6, follower_sensors=SENSORS_B), post=None),
     # config C: B's tracker + Prev sensor + two LeaderCorridor_lasers_compas (SEN:1138-1288), one scanned before the tracker's second
@@ -488,6 +491,9 @@ EPISODES = [
     ("Bes_s2_random", "B_es", 2, "random", 200),
     ("Bes_s6_chase", "B_es", 6, "chase_noisy", 200),
     ("B3_s8_chase", "B3", 8, "chase", 250),
+    ("Bastar_s1_chase", "B_astar", 1, "chase", 150),
+    ("Bastar_s6_random", "B_astar", 6, "random", 100),
+    ("Bastar_s14_chase", "B_astar", 14, "chase", 60),
     ("B6_s2_chase", "B6", 2, "chase", 250),
     ("B6_s9_random", "B6", 9, "random", 120),
     ("D_s2_chase", "D", 2, "chase", 60),

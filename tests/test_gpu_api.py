@@ -68,7 +68,7 @@ def test_game_facade_replays_a_reference_episode():
 
 
 @pytest.mark.parametrize("name", ["B_s3_chase_noisy", "E_s5_random", "D_s2_chase", "F_s7_chase", "G_s2_chase", "C_s1_chase", "L_s2_chase",
-                                  "T_s3_chase"])
+                                  "T_s3_chase", "Bastar_s1_chase", "B6_s2_chase"])
 def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
     """The whole drop-in: Game(**kwargs); seed(s); reset(); step(a)... reproduces the reference's episode with the
     scenario built by the host-side generator from the python seed alone (nothing captured from the reference)."""
