@@ -166,6 +166,20 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
             miss_ok = miss_ok && (float)(l.length - margin) == (float)l.length && (float)(l.length + margin) == (float)l.length;
         }
         P.miss_const = miss_ok ? 1 : 0;
+        int rb[2] = {0, 0};              // phase 3's per-sensor records; ray indices run over the sensors of one pass (before / after the tracker)
+        for (int k = 0; k < cfg->n_lasers; k++) {
+            const ftl_laser_cfg& l = cfg->lasers[k];
+            FtlRaySensor& rs = P.ray_sens[k];
+            const int which = l.after_tracker ? 1 : 0, ro = l.react_obstacles;
+            rs.count = l.count; rs.rbase = rb[which];
+            rs.reach2 = ((float)l.length + 2.0f) * ((float)l.length + 2.0f);
+            rs.inv_step = (float)l.count * 0.15915494309189535f; rs.inv_count = 1.0f / (float)l.count;
+            rs.off_u = (float)(l.angle_offset * deg2rad) * rs.inv_step;
+            rs.slack = 0.02f + 0.01f * (float)l.count * 0.15915494f;
+            rs.flags = ((ro == 1 || ro == 2) ? 1u : 0u) | ((ro == 1 || ro == 3) ? 2u : 0u) | (l.react_corridor ? 4u : 0u) | (l.react_green ? 8u : 0u)
+                     | (l.explicit_angles ? 16u : 0u) | (which ? 32u : 0u) | (l.compas ? 64u : 0u);
+            if (!l.compas) rb[which] += l.count;
+        }
         P.inv_nrect_dyn = (65536u + (unsigned)(P.R - 1) - 1u) / (unsigned)(P.R - 1);
     }
     if (rays > 1023) { delete h; return fail(FTL_E_INVALID, "more than 1023 rays per env (the candidate list of the ray kernel packs a ray index into 10 bits)"); }
@@ -202,7 +216,6 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         const size_t rects = (size_t)cfg->n_static + hmax + (size_t)hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
         P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + rects * 20 + (size_t)2 * cfg->corr_cap * 4 + (size_t)2 * hmax * 20 + 64
                            + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : FTL_HMAX) * 8      /* >= the HM of whichever instantiation launch() picks */ + (size_t)rays * 8
-                           + (size_t)FTL_PAIR_CAP * 4 + 16     /* candidate list of phase 3 + its counter */
                            + rects * 8 + 32);                 /* facing-edge list (u16 x 4 per rect) + edge counters */
     }
     if (P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }

@@ -183,15 +183,35 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
                 sm = 1u << a; cls = back;
             }
             if (!sm) continue;
-            // a wall farther than the rays reach cannot be hit (2 px of slack)
+            // Candidate rays, as in phase 3 of ftl_rays_kernel (float32 throughout: this only selects which rays get the reference's
+            // float64 test).  A wall whose closest approach is beyond the rays' reach (2 px of slack) cannot be hit; otherwise only the
+            // rays whose direction lies inside the arc the wall subtends at the follower (polynomial atan2, widened by >= 0.01 rad, two
+            // orders of magnitude above its error) can cross it -- typically 1-3 of the N.  A wall next to the follower keeps every ray.
+            int i0 = 0, cnt = N;
             {
-                const double ux = bx - ax, uy = by - ay, l2 = ux * ux + uy * uy;
-                double t = l2 > 0.0 ? -((ax - cx) * ux + (ay - cy) * uy) / l2 : 0.0;
-                t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
-                const double nx = ax + t * ux - cx, ny = ay + t * uy - cy, reach = Lc.length + 2.0;
-                if (nx * nx + ny * ny > reach * reach) continue;
+                const float axf = (float)(ax - cx), ayf = (float)(ay - cy), bxf = (float)(bx - cx), byf = (float)(by - cy);
+                const float ux = bxf - axf, uy = byf - ayf, l2 = __builtin_fmaf(ux, ux, uy * uy);
+                const float tt = l2 > 0.0f ? fminf(fmaxf(__fdividef(-__builtin_fmaf(axf, ux, ayf * uy), l2), 0.0f), 1.0f) : 0.0f;
+                const float nx = __builtin_fmaf(tt, ux, axf), ny = __builtin_fmaf(tt, uy, ayf);
+                const float dmin2 = __builtin_fmaf(nx, nx, ny * ny), reach = flen + 2.0f;
+                if (dmin2 > reach * reach) continue;
+                const float fN = (float)N, inv_step = fN * 0.15915494309189535f;
+                const float phis = (float)((fdir + Lc.angle_offset) * kDeg2Rad) * inv_step;
+                float uA = __builtin_fmaf(arc_atan2(ayf, axf), inv_step, -phis), uB = __builtin_fmaf(arc_atan2(byf, bxf), inv_step, -phis);
+                const float invN = __fdividef(1.0f, fN);
+                uA = __builtin_fmaf(-floorf(uA * invN), fN, uA); uB = __builtin_fmaf(-floorf(uB * invN), fN, uB);   // into [0, N) (an ulp outside is absorbed by the wrap below)
+                float diff = uB - uA; if (diff < 0.0f) diff += fN;
+                float start = uA, wd = diff;
+                if (diff > 0.5f * fN) { start = uB; wd = fN - diff; }
+                if (!(dmin2 < 4.0f || wd > 0.5f * fN - 0.05f)) {
+                    const float slack = 0.02f + 0.01f * inv_step;
+                    i0 = (int)ceilf(start - slack);
+                    cnt = (int)floorf(start + wd + slack) - i0 + 1;
+                    cnt = cnt > N ? N : cnt;
+                }
             }
-            for (int ray = 0; ray < N; ray++) {
+            for (int t = 0; t < cnt; t++) {
+                int ray = i0 + t; ray = ray < 0 ? ray + N : (ray >= N ? ray - N : ray);
                 const double2 e = s_ray[ray];
                 double d2;
                 if (wall_hit(ax, ay, bx, by, cx, cy, e.x, e.y, d2)) {
@@ -226,11 +246,13 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
         float* out = out_base + A.out_offset;
         __syncthreads();
         if (A.kind == FTL_AUX_LIDAR) {
-            const int n_ang = A.n_angles;
-            int4* s_rect = reinterpret_cast<int4*>(lds);                                          // [FTL_LIDAR_RECTS] rects in range
+            const int n_ang = A.n_angles, npts = A.points_number;
+            float4* s_rect = reinterpret_cast<float4*>(lds);                                      // [FTL_LIDAR_RECTS] rects in range: x0, x1, y0, y1 as float32
             float2* s_end = reinterpret_cast<float2*>(lds + 16 * FTL_LIDAR_RECTS);                // [n_angles] ray ends
             int* s_first = reinterpret_cast<int*>(lds + 16 * FTL_LIDAR_RECTS + 8 * n_ang);        // [n_angles] first marching point inside a rect
-            int* s_cnt = s_first + n_ang;
+            unsigned long long* s_cand = reinterpret_cast<unsigned long long*>(s_first + n_ang + (n_ang & 1));   // [n_angles] rects whose box the ray's box overlaps
+            float2* s_u = reinterpret_cast<float2*>(s_cand + n_ang);                              // [points_number] float32(u), float32(1 - u) of marching point i
+            int* s_cnt = reinterpret_cast<int*>(s_u + npts);
             if (lane == 0) *s_cnt = 0;
             __syncthreads();
             // objects_in_range (SEN:72-79): leader, static rects, bears whose nearest corner / edge mid-point is within range + 3 m
@@ -243,10 +265,17 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
                 else q = reinterpret_cast<const int4*>(P.rb_int + ((size_t)env * P.R + 2 + (o - 1 - c.n_static)) * FTL_RI_COUNT)[0];
                 const int px[8] = { q.x, q.x, q.x + q.z, q.x + q.z, q.x + (q.z >> 1), q.x, q.x + (q.z >> 1), q.x + q.z };
                 const int py[8] = { q.y, q.y + q.w, q.y, q.y + q.w, q.y, q.y + (q.w >> 1), q.y + q.w, q.y + (q.w >> 1) };
-                double dmin = 1.0e300;
+                // min over the eight points of sqrt(d2) <= range  <=>  sqrt(min d2) <= range (sqrt and its rounding are monotone); away from
+                // the threshold the squared values decide, inside a band wider than every rounding involved the square root is taken
+                double m2 = 1.0e300;
 #pragma unroll
-                for (int t = 0; t < 8; t++) dmin = fmin(dmin, euclid_f64(cx, cy, (double)px[t], (double)py[t]));
-                if (dmin <= A.in_range_px) { const int at = atomicAdd(s_cnt, 1); if (at < FTL_LIDAR_RECTS) s_rect[at] = q; }
+                for (int t = 0; t < 8; t++) { const double dx = cx - (double)px[t], dy = cy - (double)py[t]; m2 = fmin(m2, dx * dx + dy * dy); }
+                const double t2 = A.in_range_px * A.in_range_px;
+                const bool in = m2 < t2 * (1.0 - 1e-12) ? true : (m2 > t2 * (1.0 + 1e-12) ? false : sqrt(m2) <= A.in_range_px);
+                if (in) {
+                    const int at = atomicAdd(s_cnt, 1);
+                    if (at < FTL_LIDAR_RECTS) s_rect[at] = make_float4((float)q.x, (float)(q.x + q.z), (float)q.y, (float)(q.y + q.w));
+                }
             }
             for (int a = lane; a < n_ang; a += FTL_WAVE) {                         // SEN:88-104
                 double angle = -fdir;
@@ -256,21 +285,46 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
                 s_end[a] = make_float2(cxf + (float)(A.range_px * co), cyf - (float)(A.range_px * s));      // np.float32 + python float -> float32
                 s_first[a] = 0x7fffffff;
             }
+            for (int i = lane; i < npts; i += FTL_WAVE) {                          // np.linspace weights of SEN:106-110
+                const double u = (double)i / (double)npts;
+                s_u[i] = make_float2((float)u, (float)(1.0 - u));
+            }
             __syncthreads();
             if (lane == 0 && *s_cnt > FTL_LIDAR_RECTS) {
                 int* eiw = P.env_int + (size_t)env * FTL_EI_COUNT;
                 atomicOr(&eiw[FTL_EI_ERROR], (int)FTL_ERR_LIDAR_OVERFLOW); atomicOr(&eiw[FTL_EI_ERROR_STICKY], (int)FTL_ERR_LIDAR_OVERFLOW);
             }
             const int nin = min(*s_cnt, FTL_LIDAR_RECTS);
-            for (int w = lane; w < n_ang * A.points_number; w += FTL_WAVE) {       // SEN:106-121
-                const int a = w / A.points_number, i = w - a * A.points_number;
-                const double u = (double)i / (double)A.points_number;
+            // Every marching point of a ray lies between the follower and the ray's end (a float32 convex combination: within 1e-3 px of
+            // the segment), so only the rects whose box comes within 1 px of the ray's box can contain one: a bit mask per ray (the first
+            // 64 rects in range; a 65th and later ones are tested for every point).
+            for (int a = lane; a < n_ang; a += FTL_WAVE) {
                 const float2 e = s_end[a];
-                const float px = e.x * (float)u + cxf * (float)(1.0 - u), py = e.y * (float)u + cyf * (float)(1.0 - u);
+                const float x0 = fminf(e.x, cxf) - 1.0f, x1 = fmaxf(e.x, cxf) + 1.0f, y0 = fminf(e.y, cyf) - 1.0f, y1 = fmaxf(e.y, cyf) + 1.0f;
+                unsigned long long mk = 0ull;
+                for (int o = 0; o < nin && o < 64; o++) {
+                    const float4 q = s_rect[o];
+                    if (q.x <= x1 && q.y >= x0 && q.z <= y1 && q.w >= y0) mk |= 1ull << o;
+                }
+                s_cand[a] = mk;
+            }
+            __syncthreads();
+            const float inv_npts = 1.0f / (float)npts;
+            for (int w = lane; w < n_ang * npts; w += FTL_WAVE) {                  // SEN:106-121
+                int a = (int)(((float)w + 0.5f) * inv_npts);                       // w / npts (w < 2^16: the float quotient is off by far less than half a step)
+                const int i = w - a * npts;
+                const float2 e = s_end[a], uu = s_u[i];
+                const float px = e.x * uu.x + cxf * uu.y, py = e.y * uu.x + cyf * uu.y;
                 bool hit = false;
-                for (int o = 0; o < nin; o++) {
-                    const int4 q = s_rect[o];
-                    hit = hit || ((float)q.x <= px && px < (float)(q.x + q.z) && (float)q.y <= py && py < (float)(q.y + q.w));
+                unsigned long long mk = s_cand[a];
+                while (mk) {
+                    const int o = __ffsll((long long)mk) - 1; mk &= mk - 1;
+                    const float4 q = s_rect[o];
+                    hit = hit || (q.x <= px && px < q.y && q.z <= py && py < q.w);
+                }
+                for (int o = 64; o < nin; o++) {
+                    const float4 q = s_rect[o];
+                    hit = hit || (q.x <= px && px < q.y && q.z <= py && py < q.w);
                 }
                 if (hit) atomicMin(&s_first[a], i);
             }
@@ -349,7 +403,7 @@ static inline size_t ftl_aux_lds_bytes(const ftl_config& c) {
     }
     for (int j = 0; j < c.n_aux; j++) {
         const ftl_aux_cfg& a = c.aux[j];
-        const size_t b = a.kind == FTL_AUX_LIDAR ? (size_t)16 * FTL_LIDAR_RECTS + (size_t)12 * a.n_angles + 16 : a.kind == FTL_AUX_TRACK_RADAR ? (size_t)4 * a.radar_sectors : 0;
+        const size_t b = a.kind == FTL_AUX_LIDAR ? (size_t)16 * FTL_LIDAR_RECTS + (size_t)20 * a.n_angles + (size_t)8 * a.points_number + 32 : a.kind == FTL_AUX_TRACK_RADAR ? (size_t)4 * a.radar_sectors : 0;
         need = b > need ? b : need;
     }
     return (need + 15) & ~(size_t)15;

@@ -26,20 +26,20 @@
 #define FTL_WAVE 64
 #define FTL_HMAX 12         // compile-time cap on max_prev_obs (the shipped training configs use 10)
 #define FTL_MAX_RAYS 1024   // rays per env over all ray sensors (the host rejects more than 1023)
-#ifndef FTL_RAYS_COMPACT
-#define FTL_RAYS_COMPACT 0   // (measured slower) phase 3 gathers its (segment, ray) candidates in an LDS list and tests them densely, 64 per pass
-#endif
-#if FTL_RAYS_COMPACT
-#define FTL_WIDE_ARC 4       // segments facing more candidate rays than this are tested by the whole wavefront, one ray per lane
-#define FTL_PAIR_CAP 320     // candidate list: a chunk adds at most 64 * FTL_WIDE_ARC entries, flushed once fewer than that many are free
-#else
-#define FTL_WIDE_ARC 8
-#define FTL_PAIR_CAP 0
-#endif
+#define FTL_WIDE_ARC 8      // segments facing more candidate rays than this are tested by the whole wavefront, one ray per lane
 #ifndef FTL_RAYS_WPE
-#define FTL_RAYS_WPE 6      // 80 VGPRs without spills; LDS (7 KB per env) caps the CU at ~22 waves, i.e. 5.5 per SIMD
+#define FTL_RAYS_WPE 5      // 96 VGPRs; LDS (7 KB per env) caps the CU at ~22 waves, i.e. 5.5 per SIMD, and the kernel is bound by VALU issue
 #endif
 
+// per-sensor record of the ray kernel's phase 3 (built on the host in ftl_create)
+struct FtlRaySensor {
+    int32_t count, rbase;          // rays; index of ray 0 among the rays of the sensors scanned in the same pass (before / after the tracker)
+    float reach2;                  // (laser_length + 2)^2: segments whose closest approach is beyond it cannot be hit
+    float inv_step, inv_count;     // count / (2 pi), 1 / count
+    float off_u;                   // first_laser_angle_offset in units of the ray spacing
+    float slack;                   // widening of the candidate arc, in ray spacings (>= 0.01 rad)
+    uint32_t flags;                // bits 0-3: reacts to SEG_STATIC / DYNAMIC / CORRIDOR / GREEN; 16: explicit ray angles; 32: scanned after the tracker; 64: not a ray-kernel sensor (compas)
+};
 struct FtlDevParams {
     ftl_config cfg;
     int32_t n_envs, R, lasers_len, total_rays, hmax, lds_rays;
@@ -55,6 +55,7 @@ struct FtlDevParams {
     // ray directions relative to the follower's heading, host-computed with glibc: (cos, sin) of (first_laser_angle_offset + i * 360 / N)
     // -- or of ray_angles[i] -- in degrees, indexed by the ray's position over ALL ray sensors in config order
     double ray_rot[FTL_MAX_RAYS][2];
+    FtlRaySensor ray_sens[FTL_MAX_LASERS];   // phase 3 of the ray kernel: what it needs of each sensor, packed (two scalar loads)
     uint32_t inv_nrect_dyn;           // ceil(65536 / (R - 1)): source index / objects per snapshot without an integer division
     int32_t miss_const;               // 1: a ray without a hit reads float32(laser_length) exactly for every sensor (checked on the host: the
                                       // value float64 |end - origin| lies within 4e-13 of laser_length, far from a float32 rounding boundary)
@@ -422,8 +423,6 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     double2* s_ray = reinterpret_cast<double2*>(s_rmask + ((n_u32 + 3) & ~3));     // 16-byte aligned [total_rays]
     unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [total_rays][HM]
     double* s_miss = reinterpret_cast<double*>(s_best + (size_t)P.total_rays * HM);                     // [total_rays] |ray end - origin|
-    unsigned* s_pair = reinterpret_cast<unsigned*>(s_miss + P.total_rays);                              // [FTL_PAIR_CAP] ray | class << 10 | index << 12
-    int* s_np = reinterpret_cast<int*>(s_pair + FTL_PAIR_CAP);                                          // entries in s_pair
     const unsigned long long kInfBits = 0x7fefffffffffffffull;                                       // DBL_MAX: "no hit"
 
     // Round trip 1: everything that is addressed by the env index alone is requested at once -- the scalars, every ring slot
@@ -594,18 +593,19 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         continue;
 #endif
 
-        // ---- phase 3: (sensor, segment) pairs x candidate rays -----------------------------------------------------------------
+        // ---- phase 3: segments x the sensors that react to them x candidate rays ----------------------------------------------
         {
-            // flattened work list: for every sensor of the group the table entries of the classes it reacts to
-            int n_items = 0;
-            FTL_FOR_LASERS(k) {
-                if (c.lasers[k].after_tracker != which) continue;
-                const int ro = c.lasers[k].react_obstacles;
-                if (ro == 1 || ro == 2) n_items += s_ecnt[SEG_STATIC];         // the edges that face the follower (1-2 per rect)
-                if (ro == 1 || ro == 3) n_items += s_ecnt[SEG_DYNAMIC];
-                if (c.lasers[k].react_corridor) n_items += s_cnt[SEG_CORRIDOR];
-                if (c.lasers[k].react_green) n_items += s_cnt[SEG_GREEN];
-            }
+            // One SEGMENT of the table per lane.  What a segment subtends at the follower (the two end-point angles, the closest
+            // approach) is the same for every sensor, so it is worked out once; the sensors of the group then take turns, each mapping
+            // the arc to its own ray indices (parameters: one packed, host-built record per sensor, wave-uniform) and testing the rays
+            // inside it.
+            int cls_any = 0;
+#pragma nounroll
+            for (int k = 0; k < c.n_lasers; k++) { const unsigned fl = P.ray_sens[k].flags; if ((int)((fl >> 5) & 1u) == which && !(fl & 64u)) cls_any |= (int)(fl & 15u); }
+            int cq[SEG_CLASSES];
+#pragma unroll
+            for (int q = 0; q < SEG_CLASSES; q++) cq[q] = ((cls_any >> q) & 1) ? (q < 2 ? s_ecnt[q] : s_cnt[q]) : 0;
+            const int n_items = cq[0] + cq[1] + cq[2] + cq[3];
             // table entry (class mq, index m) -> segment + mask of the snapshots that contain it
             auto fetch = [&](int mq, int m, float4& sg, unsigned& sm) {
                 if (mq < 2) {                                // a facing edge of a near rect; edges in the order of sensors.py:668-671
@@ -632,138 +632,87 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     for (int j = 0; j < HM; j++) if ((smx >> j) & 1u) atomicMin(&s_best[ray * HM + j], bits);
                 }
             };
-#if FTL_RAYS_COMPACT
-            // Most table entries face no ray at all and few face more than one (46 candidates per env-step in ~106 entries on the bench
-            // workload): testing them where they are found keeps 13 % of the lanes busy.  The candidates go to a list instead and are
-            // tested 64 at a time.
-            if (lane == 0) *s_np = 0;
-            auto flush = [&]() {
-                __syncthreads();
-                const int np = __builtin_amdgcn_readfirstlane(*s_np);
-                for (int p0 = 0; p0 < np; p0 += FTL_WAVE) {
-                    const int p = p0 + lane;
-                    if (p < np) {
-                        const unsigned rec = s_pair[p];
-                        float4 sgp; unsigned smp;
-                        fetch((int)((rec >> 10) & 3u), (int)(rec >> 12), sgp, smp);
-                        test((int)(rec & 1023u), sgp, smp);
-                    }
-                }
-                __syncthreads();
-                if (lane == 0) *s_np = 0;
-                __syncthreads();
-            };
-#endif
+            const float fdir_rad = (float)(fdir * kDeg2Rad);
             for (int w0 = 0; w0 < n_items; w0 += FTL_WAVE) {
                 const int w = w0 + lane;
-#if FTL_RAYS_COMPACT
-                if (w0 > 0) { __syncthreads(); if (__builtin_amdgcn_readfirstlane(*s_np) > FTL_PAIR_CAP - FTL_WAVE * FTL_WIDE_ARC) flush(); }
-#endif
-                // decode w -> (sensor, class mq, index m within the class) + the sensor's parameters.  The flattened list is a sequence of
-                // up to 4 segments per sensor whose ends are wave-uniform: three instructions per segment find the lane's segment and its
-                // start, one select chain per sensor fetches the parameters
-                int m = -1, mq = 0, N = 1, rbase = 0; float lenf = 0.0f, phi0 = 0.0f; bool expl = false;
-                {
+                int m = -1, mq = 0;
+                {   // the flattened list is four runs whose ends are wave-uniform
                     int j = 0, start = 0, end = 0;
-                    FTL_FOR_LASERS(k) {
-                        if (c.lasers[k].after_tracker != which) continue;
-                        const int ro = c.lasers[k].react_obstacles;
-                        const bool on[SEG_CLASSES] = { ro == 1 || ro == 2, ro == 1 || ro == 3, c.lasers[k].react_corridor != 0, c.lasers[k].react_green != 0 };
 #pragma unroll
-                        for (int q = 0; q < SEG_CLASSES; q++) {
-                            end += on[q] ? (q < 2 ? s_ecnt[q] : s_cnt[q]) : 0;        // wave-uniform
-                            const bool past = w >= end;
-                            j += past ? 1 : 0; start = past ? end : start;
-                        }
+                    for (int q = 0; q < SEG_CLASSES; q++) {
+                        end += cq[q];
+                        const bool past = w >= end;
+                        j += past ? 1 : 0; start = past ? end : start;
                     }
-                    int g4 = 0, rb = 0;
-                    FTL_FOR_LASERS(k) {
-                        if (c.lasers[k].after_tracker != which) continue;
-                        if ((j >> 2) == g4) {
-                            N = c.lasers[k].count; rbase = rb; lenf = (float)c.lasers[k].length;
-                            phi0 = (float)((fdir + c.lasers[k].angle_offset) * kDeg2Rad); expl = EXPL && c.lasers[k].explicit_angles != 0;
-                        }
-                        g4 += 1; rb += c.lasers[k].count;
-                    }
-                    if (w < n_items) { m = w - start; mq = j & 3; }
+                    if (w < n_items) { m = w - start; mq = j; }
                 }
                 FTL_RTIC(3);
-                int i0 = 0, cnt = 0;
                 float4 sg = make_float4(0.f, 0.f, 0.f, 0.f); unsigned sm = 0;
-                const float fN = (float)N;
+                float angA = 0.0f, angB = 0.0f, dmin2 = 3.0e38f;
                 if (m >= 0) {
                     fetch(mq, m, sg, sm);
-                    // candidate rays: the arc [uA, uB] the segment subtends, in units of the ray spacing from ray 0
-                    const float inv_step = fN * 0.15915494309189535f;          // N / (2 pi)
-                    float ax = sg.x - cx, ay = sg.y - cy, bx = sg.z - cx, by = sg.w - cy;
-                    const float phis = phi0 * inv_step;
-                    float uA = __builtin_fmaf(arc_atan2(ay, ax), inv_step, -phis), uB = __builtin_fmaf(arc_atan2(by, bx), inv_step, -phis);
-                    const float invN = __fdividef(1.0f, fN);
-                    uA = __builtin_fmaf(-floorf(uA * invN), fN, uA); uB = __builtin_fmaf(-floorf(uB * invN), fN, uB);      // into [0, N) (an ulp outside is absorbed by the wrap below)
-                    float diff = uB - uA; if (diff < 0.0f) diff += fN;
-                    float start = uA, wd = diff;
-                    if (diff > 0.5f * fN) { start = uB; wd = fN - diff; }
-                    // closest approach of the segment to the follower (culling only: 2 px of slack below)
-                    float ex_ = bx - ax, ey_ = by - ay;
-                    float l2 = __builtin_fmaf(ex_, ex_, ey_ * ey_);
-                    float tt = l2 > 0.0f ? fminf(fmaxf(__fdividef(-__builtin_fmaf(ax, ex_, ay * ey_), l2), 0.0f), 1.0f) : 0.0f;
-                    float nx = __builtin_fmaf(tt, ex_, ax), ny = __builtin_fmaf(tt, ey_, ay);
-                    float dmin2 = __builtin_fmaf(nx, nx, ny * ny);
-                    const float reachf = lenf + 2.0f;
-                    if (dmin2 > reachf * reachf) { i0 = 0; cnt = 0; }                     // wholly beyond this sensor's reach
-                    else if (expl || dmin2 < 4.0f || wd > 0.5f * fN - 0.05f) { i0 = 0; cnt = N; }   // through / next to the origin, or rays
-                                                                                          // at explicit angles (<= 7 of them): every ray
-                    else {
-                        const float slack = 0.02f + 0.01f * fN * 0.15915494f;             // >= 0.01 rad, far above float error
-                        i0 = (int)ceilf(start - slack);
-                        cnt = (int)floorf(start + wd + slack) - i0 + 1;
-                        cnt = cnt > N ? N : cnt;
-                    }
+                    const float ax = sg.x - cx, ay = sg.y - cy, bx = sg.z - cx, by = sg.w - cy;
+                    angA = arc_atan2(ay, ax); angB = arc_atan2(by, bx);
+                    // closest approach of the segment to the follower (culling only: 2 px of slack in the records' reach)
+                    const float ex_ = bx - ax, ey_ = by - ay;
+                    const float l2 = __builtin_fmaf(ex_, ex_, ey_ * ey_);
+                    const float tt = l2 > 0.0f ? fminf(fmaxf(__fdividef(-__builtin_fmaf(ax, ex_, ay * ey_), l2), 0.0f), 1.0f) : 0.0f;
+                    const float nx = __builtin_fmaf(tt, ex_, ax), ny = __builtin_fmaf(tt, ey_, ay);
+                    dmin2 = __builtin_fmaf(nx, nx, ny * ny);
                 }
                 FTL_RTIC(4);
-#if defined(FTL_RAYS_STOP) && (FTL_RAYS_STOP == 5 || FTL_RAYS_STOP == 6)   // diagnostic: decode + fetch (+ arc for 5) only, no ray tests
-                if (FTL_RAYS_STOP == 6) cnt = (int)(sg.x + sg.y + sg.z + sg.w) == 0x7fffffff ? 1 : 0; else cnt = cnt == 0x7fffffff ? 1 : 0;
+#pragma nounroll
+                for (int k = 0; k < c.n_lasers; k++) {
+                    const FtlRaySensor rs = P.ray_sens[k];                 // wave-uniform: two scalar loads
+                    if ((int)((rs.flags >> 5) & 1u) != which || (rs.flags & 64u)) continue;
+                    const int N = rs.count, rbase = rs.rbase;
+                    int i0 = 0, cnt = 0;
+                    if (m >= 0 && ((rs.flags >> mq) & 1u) && !(dmin2 > rs.reach2)) {      // the sensor reacts to this class and can reach the segment
+                        // candidate rays: the arc [uA, uB] the segment subtends, in units of the ray spacing from ray 0
+                        const float fN = (float)N;
+                        const float phis = __builtin_fmaf(fdir_rad, rs.inv_step, rs.off_u);
+                        float uA = __builtin_fmaf(angA, rs.inv_step, -phis), uB = __builtin_fmaf(angB, rs.inv_step, -phis);
+                        uA = __builtin_fmaf(-floorf(uA * rs.inv_count), fN, uA); uB = __builtin_fmaf(-floorf(uB * rs.inv_count), fN, uB);   // into [0, N) (an ulp outside is absorbed by the wrap below)
+                        float diff = uB - uA; if (diff < 0.0f) diff += fN;
+                        float start = uA, wd = diff;
+                        if (diff > 0.5f * fN) { start = uB; wd = fN - diff; }
+                        if ((rs.flags & 16u) || dmin2 < 4.0f || wd > 0.5f * fN - 0.05f) { i0 = 0; cnt = N; }   // through / next to the origin, or rays
+                                                                                              // at explicit angles (<= 7 of them): every ray
+                        else {
+                            i0 = (int)ceilf(start - rs.slack);                              // slack >= 0.01 rad, far above float error
+                            cnt = (int)floorf(start + wd + rs.slack) - i0 + 1;
+                            cnt = cnt > N ? N : cnt;
+                        }
+                    }
+#if defined(FTL_RAYS_STOP) && FTL_RAYS_STOP == 5   // diagnostic: decode + fetch + arcs only, no ray tests
+                    cnt = cnt == 0x7fffffff ? 1 : 0;
 #endif
 #ifdef FTL_PROFILE_RAYS
-                if (threadIdx.x == 0) { s_rcyc[8] += 1; }
-                { int mc = cnt; for (int o = 32; o >= 1; o >>= 1) mc = max(mc, __shfl_xor(mc, o)); int ni = __popcll(__ballot(m >= 0)); int sc = cnt; for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o); int n4 = __popcll(__ballot(cnt > 4)); if (threadIdx.x == 0) { s_rcyc[9] += mc; s_rcyc[10] += sc; s_rcyc[11] += ni; s_rcyc[12] += (mc <= 2); s_rcyc[13] += (mc > 2 && mc <= 4); s_rcyc[14] += (mc > 4 && mc <= 8); s_rcyc[15] += (mc > 8); } (void)n4; }
+                    if (threadIdx.x == 0) { s_rcyc[8] += 1; }
+                    { int mc = cnt; for (int o = 32; o >= 1; o >>= 1) mc = max(mc, __shfl_xor(mc, o)); int ni = __popcll(__ballot(m >= 0)); int sc = cnt; for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o); if (threadIdx.x == 0) { s_rcyc[9] += mc; s_rcyc[10] += sc; s_rcyc[11] += ni; s_rcyc[12] += (mc <= 2); s_rcyc[13] += (mc > 2 && mc <= 4); s_rcyc[14] += (mc > 4 && mc <= 8); s_rcyc[15] += (mc > 8); } }
 #endif
-                // A segment next to the follower faces many rays (up to all N): one lane looping over them would hold the
-                // whole wavefront for that many test iterations.  Such segments (rare: a few per cent of the chunks) are
-                // handed to the wavefront instead -- broadcast the segment, one ray per lane.
-                unsigned long long wide = __ballot(cnt > FTL_WIDE_ARC);
-                while (wide) {
-                    const int L = __ffsll((long long)wide) - 1; wide &= wide - 1;
-                    const float4 sgL = make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.x), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.y), L)),
-                                                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.z), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.w), L)));
-                    const unsigned smL = (unsigned)__builtin_amdgcn_readlane((int)sm, L);
-                    const int i0L = __builtin_amdgcn_readlane(i0, L), cntL = __builtin_amdgcn_readlane(cnt, L);
-                    const int NL = __builtin_amdgcn_readlane(N, L), rbL = __builtin_amdgcn_readlane(rbase, L);
-                    for (int t = lane; t < cntL; t += FTL_WAVE) {
-                        int i = i0L + t; i = i < 0 ? i + NL : (i >= NL ? i - NL : i);
-                        test(rbL + i, sgL, smL);
+                    // A segment next to the follower faces many rays (up to all N): one lane looping over them would hold the
+                    // whole wavefront for that many test iterations.  Such segments (rare: a few per cent of the chunks) are
+                    // handed to the wavefront instead -- broadcast the segment, one ray per lane.
+                    unsigned long long wide = __ballot(cnt > FTL_WIDE_ARC);
+                    while (wide) {
+                        const int L = __ffsll((long long)wide) - 1; wide &= wide - 1;
+                        const float4 sgL = make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.x), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.y), L)),
+                                                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.z), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.w), L)));
+                        const unsigned smL = (unsigned)__builtin_amdgcn_readlane((int)sm, L);
+                        const int i0L = __builtin_amdgcn_readlane(i0, L), cntL = __builtin_amdgcn_readlane(cnt, L);
+                        for (int t = lane; t < cntL; t += FTL_WAVE) {
+                            int i = i0L + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
+                            test(rbase + i, sgL, smL);
+                        }
                     }
-                }
-                const int own = cnt > FTL_WIDE_ARC ? 0 : cnt;
-#if FTL_RAYS_COMPACT
-                if (own > 0) {
-                    const int pos = atomicAdd(s_np, own);
-                    const unsigned rec = ((unsigned)mq << 10) | ((unsigned)m << 12);
+                    const int own = cnt > FTL_WIDE_ARC ? 0 : cnt;
                     for (int t = 0; t < own; t++) {
                         int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
-                        s_pair[pos + t] = rec | (unsigned)(rbase + i);
+                        test(rbase + i, sg, sm);
                     }
                 }
-#else
-                for (int t = 0; t < own; t++) {
-                    int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
-                    test(rbase + i, sg, sm);
-                }
-#endif
             }
-#if FTL_RAYS_COMPACT
-            flush();
-#endif
         }
         FTL_RTIC(5);
 #if defined(FTL_RAYS_STOP) && FTL_RAYS_STOP == 4
