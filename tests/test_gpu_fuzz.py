@@ -1,0 +1,170 @@
+"""Randomised configs against the oracle: the golden episodes and the named configs pin a dozen points of the config space; this
+walks through it -- sensor sets in random dict order around the tracker (both scan passes), every react_to_* combination, history
+lengths 1-12, pad_sectors, 0-4 dynamic obstacles (the 4- and 8-lane instantiations of the frame kernel), frame counts, regimes,
+random frames per step, early stopping.  Every output of every env and step is compared with oracle/ftl_oracle.c, which the golden
+episodes pin to the reference.  The draws are seeded: a failure names the seed that rebuilds its config."""
+import numpy as np
+import pytest
+import torch
+
+from continiousenvironment_follower_leader_amd import make_config
+from oracle_batch import OracleBatch, pool_scenarios
+from test_gpu_configs import _actions, _compare_with_oracle, _vec
+
+pytestmark = pytest.mark.gpu
+
+TRACKER = dict(sensor_class="LeaderPositionsTracker_v2", eat_close_points=False, generate_corridor=True, saving_period=8,
+               start_corridor_behind_follower=True, corridor_length=250, corridor_width=30)
+
+
+def _ray_sensor(rng, kind):
+    react = dict(react_to_green_zone=bool(rng.integers(2)), react_to_safe_corridor=bool(rng.integers(2)),
+                 react_to_obstacles=[True, False, "static", "dynamic", "all"][rng.integers(5)])
+    if not (react["react_to_green_zone"] or react["react_to_safe_corridor"] or react["react_to_obstacles"]):
+        react["react_to_safe_corridor"] = True
+    if kind == "prev":
+        return dict(sensor_class="LeaderCorridor_Prev_lasers_v2", lasers_count=int(rng.choice([12, 20, 24, 36])),
+                    laser_length=int(rng.integers(60, 220)), max_prev_obs=int(rng.integers(1, 13)), use_prev_obs=True,
+                    pad_sectors=bool(rng.integers(3) == 0), **react)
+    if kind == "v2":
+        return dict(sensor_class="LeaderCorridor_lasers_v2", lasers_count=int(rng.choice([12, 20, 24, 36])),
+                    laser_length=int(rng.integers(60, 220)), **react)
+    if kind == "front":
+        return dict(sensor_class="LeaderCorridor_lasers", front_lasers_count=int(rng.choice([3, 5])), back_lasers_count=int(rng.choice([0, 2])),
+                    laser_length=int(rng.integers(60, 180)), **react)
+    return dict(sensor_class="LeaderCorridor_lasers_compas", lasers_count=int(rng.choice([12, 20, 36])), laser_length=int(rng.integers(60, 160)),
+                max_prev_obs=int(rng.integers(1, 9)), pad_sectors=False, react_to_green_zone=True, react_to_safe_corridor=True,
+                react_to_obstacles=False)
+
+
+def _aux_sensor(rng, kind):
+    if kind == "lidar":
+        return dict(sensor_class="LaserSensor", available_angle=int(rng.choice([90, 180, 360])), angle_step=int(rng.choice([10, 15, 30])),
+                    points_number=int(rng.choice([8, 10, 20])), sensor_range=int(rng.integers(2, 6)), return_only_distances=bool(rng.integers(2)))
+    if kind == "vector":
+        return dict(sensor_class="LeaderTrackDetector_vector", position_sequence_length=int(rng.integers(4, 40)),
+                    detectable_positions=["new", "old"][rng.integers(2)])
+    return dict(sensor_class="LeaderTrackDetector_radar", position_sequence_length=int(rng.integers(4, 40)),
+                detectable_positions=["new", "old", "near"][rng.integers(3)], radar_sectors_number=int(rng.choice([8, 18, 36])))
+
+
+def draw_config(seed):
+    rng = np.random.default_rng(1000 + seed)
+    entries = []
+    for k in range(int(rng.integers(1, 4))):                    # 1-3 segment ray sensors
+        entries.append(("rays%d" % k, _ray_sensor(rng, ["prev", "prev", "v2", "front"][rng.integers(4)])))
+    if rng.integers(3) == 0:
+        entries.append(("compas", _ray_sensor(rng, "compas")))
+    for k in range(int(rng.integers(0, 3))):                    # 0-2 of lidar / leader-track detectors
+        entries.append(("aux%d" % k, _aux_sensor(rng, ["lidar", "vector", "radar"][rng.integers(3)])))
+    order = rng.permutation(len(entries))
+    at = int(rng.integers(0, len(entries) + 1))                 # the tracker's dict position: sensors before it see the first scan only
+    sensors = {}
+    for pos, j in enumerate(order):
+        if pos == at:
+            sensors["LeaderPositionsTracker_v2"] = dict(TRACKER, saving_period=int(rng.choice([4, 8])))
+        sensors[entries[j][0]] = entries[j][1]
+    if "LeaderPositionsTracker_v2" not in sensors:
+        sensors["LeaderPositionsTracker_v2"] = dict(TRACKER, saving_period=int(rng.choice([4, 8])))
+    bears = int(rng.integers(0, 5))
+    hist = max([s.get("max_prev_obs", 1) for s in sensors.values()] + [1])
+    if hist * (1 + bears) > 64:                                 # one wavefront of snapshot rects (ftl_create rejects more)
+        bears = 64 // hist - 1
+    kw = dict(follower_sensors=sensors, bear_number=bears, add_bear=bears > 0, obstacle_number=int(rng.choice([10, 35, 60])),
+              frames_per_step=int(rng.choice([3, 5, 10])), max_distance=float(rng.choice([3, 4, 5])), min_distance=float(rng.choice([0.5, 1, 1.5])),
+              max_dev=float(rng.choice([0.5, 1, 1.5])), warm_start=int(rng.choice([0, 50, 500])), max_steps=int(rng.choice([120, 5000])),
+              aggregate_reward=bool(rng.integers(4) == 0), move_bear_v4=bool(rng.integers(2)), rng_seed=int(seed), env_id_base=100 * seed)
+    if rng.integers(3) == 0:
+        kw["leader_speed_regime"] = {0: [0.2, 1], 60: 0.5, 150: [0.6, 1.0]}
+    if rng.integers(4) == 0:
+        kw["leader_acceleration_regime"] = {0: 0, 40: 0.002, 90: -0.002, 140: 0}
+    if rng.integers(4) == 0:
+        kw["random_frames_per_step"] = [3, 9]
+    if rng.integers(3) == 0:
+        kw["early_stopping"] = {"max_distance_coef": 1.5, "low_reward": -80}
+    return kw
+
+
+def _radar_knife_edges(env, cfg):
+    """(env, column) mask of LeaderTrackDetector_radar readings that sit on a knife edge.  A tracked point whose angle to the
+    follower's right-hand vector equals a sector boundary to within rounding goes to one sector or its neighbour depending on the
+    last bit of cos / sin of the heading (SEN:423-476: `ar >= sa * t and ar < sa * (t + 1)` on arccos values) -- which libm, numpy
+    SIMD kernel or device routine produced it.  After reset() this is the rule, not the exception: the initial trajectory runs
+    straight ahead of the follower, 90 degrees from the right-hand vector, and 90 degrees is a boundary for every even sector count.
+    Such readings are excluded from the comparison (and counted); everything else must match."""
+    from continiousenvironment_follower_leader_amd import abi
+    mask = np.zeros((env.n, max(cfg.lasers_len, 1)), bool)
+    radars = [j for j in range(cfg.c.n_aux) if cfg.c.aux[j].kind == abi.AUX_TRACK_RADAR]
+    if not radars:
+        return mask
+    ei = env.state_field("env_int").cpu().numpy()
+    pos = env.state_field("rb_pos").cpu().numpy().reshape(env.n, cfg.n_robots, 2)[:, 1].astype(np.float64)
+    fdir = env.state_field("rb_dbl").cpu().numpy().reshape(env.n, cfg.n_robots, abi.RD_COUNT)[:, 1, abi.RD_DIRECTION]
+    hist = env.state_field("hist").cpu().numpy().reshape(env.n, -1, 2)
+    cap = hist.shape[1]
+    for j in radars:
+        A = cfg.c.aux[j]
+        lo = ei[:, abi.EI_CORR_LO if A.after_tracker else abi.EI_HW0_LO]; hi = ei[:, abi.EI_CORR_HI if A.after_tracker else abi.EI_HW0_HI]
+        sa = np.pi / A.radar_sectors
+        for e in range(env.n):
+            n = int(hi[e] - lo[e]); s0, s1 = 0, n
+            if A.detectable == 0: s0 = max(n - A.seq_len, 0)
+            elif A.detectable == 1: s1 = min(n, A.seq_len)
+            if s1 <= s0:
+                continue
+            p = hist[e, (lo[e] + np.arange(s0, s1)) & (cap - 1)]
+            v = p - pos[e]
+            r = np.radians((fdir[e] + 90.0) % 360.0)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                q = np.arccos(np.clip((v[:, 0] * np.cos(r) + v[:, 1] * np.sin(r)) / np.hypot(v[:, 0], v[:, 1]), -1, 1)) / sa
+            if np.any(np.abs(q - np.rint(q)) < 1e-6):
+                mask[e, A.out_offset:A.out_offset + A.radar_sectors] = True
+    return mask
+
+
+def _compare(env, ora, cfg, tag, stats):
+    edge = _radar_knife_edges(env, cfg)
+    if edge.any():
+        las = env.lasers.cpu().numpy()
+        L = cfg.lasers_len
+        stats[0] += int((edge[:, :L] & (las[:, :L] != ora.lasers[:, :L])).any(1).sum())
+        ora.lasers[:, :L][edge[:, :L]] = las[:, :L][edge[:, :L]]
+    stats[1] += env.n
+    _compare_with_oracle(env, ora, cfg, tag)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_config_matches_oracle(seed):
+    from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool
+    kw = draw_config(seed)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cfg = make_config(route_cap=256, **kw)
+    n, steps = 96, 60
+    pool = ScenarioPool.generate(cfg, np.arange(16) + 50 * seed, "cuda:0")
+    env = _vec(n, cfg, pool)
+    scen = pool_scenarios(pool)
+    idx = np.arange(n) % pool.n
+    env.reset(torch.from_numpy(idx.astype(np.int32)))
+    ora = OracleBatch(cfg, n, env_id_base=100 * seed)
+    ora.reset(scen, idx)
+    stats = [0, 0]            # radar readings excused as knife edges, env-steps compared
+    err_seen = np.zeros(n, np.int64)
+    _compare(env, ora, cfg, (seed, "reset"), stats)
+    for t in range(steps):
+        a = _actions(cfg, n, t, "mixed" if t % 3 == 2 else "random", seed=seed)
+        env.step(torch.tensor(a, dtype=torch.float64, device="cuda:0"))
+        ora.step(a)
+        _compare(env, ora, cfg, (seed, t, sorted(kw["follower_sensors"])), stats)
+        err_seen |= ora.counters()[2]
+        d = ora.done.astype(bool)
+        if d.any() and t % 12 == 11:                # masked reset of the finished envs on both sides
+            idx = np.where(d, (idx + n) % pool.n, idx)
+            env.reset(torch.from_numpy(idx.astype(np.int32)), mask=torch.from_numpy(d.astype(np.uint8)))
+            ora.reset(scen, idx, mask=d)
+            _compare(env, ora, cfg, (seed, t, "masked reset"), stats)
+    rep = env.error_report()             # sticky: the bits of every episode since the handle was created
+    assert rep[0] == int((err_seen != 0).sum()) and rep[1] == int(np.bitwise_or.reduce(err_seen)), (seed, rep, np.unique(err_seen))
+    assert stats[0] <= 0.05 * stats[1], (seed, stats)        # knife edges are the exception
+    env.close()
