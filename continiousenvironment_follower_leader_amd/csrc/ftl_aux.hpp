@@ -106,8 +106,12 @@ __device__ __forceinline__ bool wall_hit(double ax, double ay, double bx, double
 
 // One wavefront per env.  LDS: one scratch area shared by the sensors, used one after the other; its size is the largest any sensor of
 // the config needs (ftl_aux_lds_bytes below, passed at launch).
+#define FTL_COMPAS_STAGE 128         // corridor points the compas sensors stage in LDS (a longer span is read from global memory)
 #define FTL_LIDAR_RECTS 128          // objects in range of one lidar (more raise FTL_ERR_LIDAR_OVERFLOW and are ignored)
-__global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
+#ifndef FTL_AUX_WPE
+#define FTL_AUX_WPE 5
+#endif
+__global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     using namespace ftl;
     extern __shared__ __align__(16) unsigned char lds[];
     const FtlDevParams& P = *Pp;
@@ -124,6 +128,34 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
     const unsigned long long kInf = 0x7fefffffffffffffull;
 
     // ---------------- LeaderCorridor_lasers_compas ------------------------------------------------------------------------------
+    // Everything the compas sensors read from global memory arrives in three round trips, whatever their number: the env scalars, the
+    // corridor windows of all snapshot slots (both scan passes), then the corridor points those windows span, staged as float64 in
+    // LDS.  The sensors themselves work on LDS only (this kernel is bound by its wavefronts' serial latency, not by arithmetic).
+    bool any_compas = false;
+    for (int k = 0; k < c.n_lasers; k++) any_compas = any_compas || c.lasers[k].compas != 0;
+    if (any_compas) {
+        const int snap_count = ei[FTL_EI_SNAP_COUNT], snap_head = ei[FTL_EI_SNAP_HEAD], scan_ok = ei[FTL_EI_SCAN_OK];
+        const int newest = (snap_head == 0 ? P.hmax : snap_head) - 1;
+        int* s_winall = reinterpret_cast<int*>(lds);                                            // [hmax][4]: lo, hi of pass 0, lo, hi of pass 1
+        double* s_c64 = reinterpret_cast<double*>(lds + (((size_t)P.hmax * 16 + 31) & ~(size_t)31));   // [FTL_COMPAS_STAGE][4] corridor points
+        unsigned char* scratch = reinterpret_cast<unsigned char*>(s_c64 + 4 * FTL_COMPAS_STAGE);
+        const int nvalid = snap_count < P.hmax ? snap_count : P.hmax;
+        if (lane < P.hmax * 4) s_winall[lane] = P.snap_win[(size_t)env * P.hmax * 4 + lane];
+        __syncthreads();
+        int passes = 0;                                   // scan passes (before / after the tracker's own dict entry) that have a compas sensor
+        for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].compas) passes |= 1 << (c.lasers[k].after_tracker ? 1 : 0);
+        int base = 0x7fffffff, top = 0;
+        for (int a = 0; a < nvalid; a++) {
+            int slot = newest - a; slot += slot < 0 ? P.hmax : 0;
+            for (int w = 0; w < 2; w++) if ((passes >> w) & 1) { base = min(base, s_winall[4 * slot + 2 * w]); top = max(top, s_winall[4 * slot + 2 * w + 1]); }
+        }
+        const bool staged = nvalid > 0 && top - base <= FTL_COMPAS_STAGE;      // (the v1 tracker's corridor is never trimmed: it can outgrow the stage)
+        if (staged) for (int p = base + lane; p < top; p += FTL_WAVE) {
+            const double4 q = *reinterpret_cast<const double4*>(corr_slot(P, env, p));
+            *reinterpret_cast<double4*>(s_c64 + 4 * (p - base)) = q;
+        }
+        __syncthreads();
+        auto corr_pt = [&](int p) -> const double* { return staged ? s_c64 + 4 * (p - base) : corr_slot(P, env, p); };
     for (int k = 0; k < c.n_lasers; k++) {
         const ftl_laser_cfg& Lc = c.lasers[k];
         if (!Lc.compas) continue;
@@ -131,7 +163,7 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
         float* out = out_base + Lc.out_offset;
         float* pol = (C.out.policy_obs && P.pol_off[k] >= 0) ? C.out.policy_obs + (size_t)env * P.pol_h * P.pol_width + P.pol_off[k] : nullptr;
         const float flen = (float)Lc.length;
-        if (!((ei[FTL_EI_SCAN_OK] >> which) & 1)) {      // SEN:1192/1244: the reference raises UnboundLocalError (error bit set by the tracker code)
+        if (!((scan_ok >> which) & 1)) {      // SEN:1192/1244: the reference raises UnboundLocalError (error bit set by the tracker code)
             for (int i = lane; i < H * W; i += FTL_WAVE) {
                 const float v = (i % W) < N ? flen : 0.0f;
                 out[i] = v;
@@ -139,19 +171,16 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
             }
             continue;
         }
-        double2* s_ray = reinterpret_cast<double2*>(lds);                                   // [N]
+        double2* s_ray = reinterpret_cast<double2*>(scratch);                               // [N]
         unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + N);      // [N][H]: squared distance, wall class in the 2 low bits
         int* s_win = reinterpret_cast<int*>(s_best + N * H);                                // [H][2]
         __syncthreads();
-        const int snap_count = ei[FTL_EI_SNAP_COUNT], snap_head = ei[FTL_EI_SNAP_HEAD];
-        const int newest = (snap_head == 0 ? P.hmax : snap_head) - 1;
         const int nsnap = snap_count < H ? snap_count : H;
         if (lane < H) {
             int lo = 0, hi = 0;
             if (lane < nsnap) {
                 int slot = newest - lane; slot += slot < 0 ? P.hmax : 0;
-                const int* sw = P.snap_win + ((size_t)env * P.hmax + slot) * 4 + 2 * which;
-                lo = sw[0]; hi = sw[1];
+                lo = s_winall[4 * slot + 2 * which]; hi = s_winall[4 * slot + 2 * which + 1];
             }
             s_win[2 * lane] = lo; s_win[2 * lane + 1] = hi;
         }
@@ -167,18 +196,18 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
         const int n_wall = nsnap > 0 ? 2 * max(umax - umin - 1, 0) : 0;
         const int n_items = n_wall + 2 * nsnap;
         // one item per lane -- a wall shared by every snapshot whose window holds both of its points, or an end cap of ONE snapshot --
-        // against every ray in turn (the wall stays in registers; N <= 36)
+        // against its candidate rays (the wall stays in registers; N <= 36)
         for (int item = lane; item < n_items; item += FTL_WAVE) {
             double ax, ay, bx, by; unsigned sm = 0; int cls;
             if (item < n_wall) {
                 const int p = umin + (item >> 1), side = item & 1;             // side 0: right wall (class 3), 1: left wall (class 2)
                 for (int a = 0; a < nsnap; a++) if (s_win[2 * a] <= p && p + 1 < s_win[2 * a + 1]) sm |= 1u << a;
-                const double* u = corr_slot(P, env, p); const double* v = corr_slot(P, env, p + 1);
+                const double* u = corr_pt(p); const double* v = corr_pt(p + 1);
                 ax = u[2 * side]; ay = u[2 * side + 1]; bx = v[2 * side]; by = v[2 * side + 1];
                 cls = side ? 2 : 3;
             } else {
                 const int a = (item - n_wall) >> 1, back = (item - n_wall) & 1;   // front = corridor[-1] (class 0), back = corridor[0] (class 1)
-                const double* u = corr_slot(P, env, back ? s_win[2 * a] : s_win[2 * a + 1] - 1);
+                const double* u = corr_pt(back ? s_win[2 * a] : s_win[2 * a + 1] - 1);
                 ax = u[0]; ay = u[1]; bx = u[2]; by = u[3];
                 sm = 1u << a; cls = back;
             }
@@ -238,6 +267,7 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
             if (pol) pol[(H - 1 - a) * P.pol_width + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
         }
         __syncthreads();
+    }
     }
 
     // ---------------- LaserSensor / LeaderTrackDetector_* --------------------------------------------------------------------------
@@ -397,8 +427,11 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_aux_kernel(const FtlDevParams* _
 // dynamic LDS of ftl_aux_kernel for a config
 static inline size_t ftl_aux_lds_bytes(const ftl_config& c) {
     size_t need = 64;
+    int hmax = 1;
+    for (int k = 0; k < c.n_lasers; k++) hmax = c.lasers[k].history > hmax ? c.lasers[k].history : hmax;     // = FtlDevParams::hmax
     for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].compas) {
-        const size_t b = (size_t)c.lasers[k].count * 16 + (size_t)c.lasers[k].count * c.lasers[k].history * 8 + (size_t)c.lasers[k].history * 8;
+        const size_t b = (((size_t)hmax * 16 + 31) & ~(size_t)31) + (size_t)32 * FTL_COMPAS_STAGE
+                       + (size_t)c.lasers[k].count * 16 + (size_t)c.lasers[k].count * c.lasers[k].history * 8 + (size_t)c.lasers[k].history * 8;
         need = b > need ? b : need;
     }
     for (int j = 0; j < c.n_aux; j++) {
