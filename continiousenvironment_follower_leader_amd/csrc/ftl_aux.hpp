@@ -282,8 +282,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const Ft
             int* s_first = reinterpret_cast<int*>(lds + 16 * FTL_LIDAR_RECTS + 8 * n_ang);        // [n_angles] first marching point inside a rect
             unsigned long long* s_cand = reinterpret_cast<unsigned long long*>(s_first + n_ang + (n_ang & 1));   // [n_angles] rects whose box the ray's box overlaps
             float2* s_u = reinterpret_cast<float2*>(s_cand + n_ang);                              // [points_number] float32(u), float32(1 - u) of marching point i
-            int* s_cnt = reinterpret_cast<int*>(s_u + npts);
-            if (lane == 0) *s_cnt = 0;
+            int* s_list = reinterpret_cast<int*>(s_u + npts);                                     // [n_angles] rays with a non-empty candidate mask
+            int* s_cnt = s_list + n_ang;                                                          // [2] rects in range, rays to march
+            if (lane < 2) s_cnt[lane] = 0;
             __syncthreads();
             // objects_in_range (SEN:72-79): leader, static rects, bears whose nearest corner / edge mid-point is within range + 3 m
             const int nobj = 1 + c.n_static + c.n_bears;
@@ -337,12 +338,14 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const Ft
                     if (q.x <= x1 && q.y >= x0 && q.z <= y1 && q.w >= y0) mk |= 1ull << o;
                 }
                 s_cand[a] = mk;
+                if (mk || nin > 64) s_list[atomicAdd(s_cnt + 1, 1)] = a;                       // only these rays can hit anything: the others are not marched
             }
             __syncthreads();
             const float inv_npts = 1.0f / (float)npts;
-            for (int w = lane; w < n_ang * npts; w += FTL_WAVE) {                  // SEN:106-121
-                int a = (int)(((float)w + 0.5f) * inv_npts);                       // w / npts (w < 2^16: the float quotient is off by far less than half a step)
-                const int i = w - a * npts;
+            const int n_march = s_cnt[1] * npts;
+            for (int w = lane; w < n_march; w += FTL_WAVE) {                       // SEN:106-121
+                const int la = (int)(((float)w + 0.5f) * inv_npts);                // w / npts (w < 2^16: the float quotient is off by far less than half a step)
+                const int i = w - la * npts, a = s_list[la];
                 const float2 e = s_end[a], uu = s_u[i];
                 const float px = e.x * uu.x + cxf * uu.y, py = e.y * uu.x + cyf * uu.y;
                 bool hit = false;
@@ -405,13 +408,28 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const Ft
                 const double nd = sqrt(__builtin_fma(dvy, dvy, dvx * dvx)), nr = sqrt(__builtin_fma(rvy, rvy, rvx * rvx));
                 const bool any64 = !v1 && (lo + s0) < ei[FTL_EI_SEED_END] && s0 < s1;   // a float64 point in the slice makes the whole array float64
                 const double sa = 3.141592653589793 / (double)A.radar_sectors;
+                const float inv_sa = (float)((double)A.radar_sectors / 3.141592653589793);
                 for (int i = s0 + lane; i < s1; i += FTL_WAVE) {
                     double hx, hy; point(i, hx, hy);
                     double vx, vy, dist;
                     if (any64) { vx = hx - cx; vy = hy - cy; dist = sqrt(vx * vx + vy * vy); }
                     else { const float fx = (float)hx - cxf, fy = (float)hy - cyf; vx = (double)fx; vy = (double)fy; dist = (double)sqrtf(fx * fx + fy * fy); }
-                    const double ad = acos((vx * dvx + vy * dvy) / (dist * nd));
-                    double ar = acos((vx * rvx + vy * rvy) / (dist * nr));
+                    const double dot_d = vx * dvx + vy * dvy, dot_r = vx * rvx + vy * rvy;
+                    // The sector is floor(angle to the right-hand vector / sa) for points ahead of the follower (SEN:463-476).  A float32
+                    // atan2 of (|cross|, dot) gives that angle to ~3e-7 rad (the reference's own arccos(dot / norms) is within 2e-8 of it);
+                    // unless it lies within 4e-6 rad of a sector boundary, or the point sits within 1e-9 of the follower's side-to-side
+                    // axis (where "ahead" is decided), the sector is settled without the two float64 arccos of the reference expression.
+                    const float ang = atan2f(fabsf((float)(vx * rvy - vy * rvx)), (float)dot_r);
+                    const float qf = ang * inv_sa;
+                    const float tf = floorf(qf);
+                    const bool settled = dist > 0.0 && fabs(dot_d) > 1e-9 * dist && (qf - tf) > 4e-6f * inv_sa && (tf + 1.0f - qf) > 4e-6f * inv_sa;
+                    if (settled) {
+                        const int t = (int)tf;
+                        if (dot_d > 0.0 && t < S) atomicMin(&s_rad[t], __float_as_uint((float)dist));     // behind the follower: ar < 0, no sector
+                        continue;
+                    }
+                    const double ad = acos(dot_d / (dist * nd));
+                    double ar = acos(dot_r / (dist * nr));
                     if (ad > 3.141592653589793 / 2) ar = -ar;
                     int s = (int)floor(ar / sa);                                   // candidate sector; the reference's own comparisons decide
                     for (int t = s - 1; t <= s + 1; t++)
@@ -436,7 +454,7 @@ static inline size_t ftl_aux_lds_bytes(const ftl_config& c) {
     }
     for (int j = 0; j < c.n_aux; j++) {
         const ftl_aux_cfg& a = c.aux[j];
-        const size_t b = a.kind == FTL_AUX_LIDAR ? (size_t)16 * FTL_LIDAR_RECTS + (size_t)20 * a.n_angles + (size_t)8 * a.points_number + 32 : a.kind == FTL_AUX_TRACK_RADAR ? (size_t)4 * a.radar_sectors : 0;
+        const size_t b = a.kind == FTL_AUX_LIDAR ? (size_t)16 * FTL_LIDAR_RECTS + (size_t)24 * a.n_angles + (size_t)8 * a.points_number + 32 : a.kind == FTL_AUX_TRACK_RADAR ? (size_t)4 * a.radar_sectors : 0;
         need = b > need ? b : need;
     }
     return (need + 15) & ~(size_t)15;
