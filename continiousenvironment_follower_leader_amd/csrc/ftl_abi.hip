@@ -216,8 +216,11 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         const size_t rects = (size_t)cfg->n_static + hmax + (size_t)hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
         P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + rects * 20 + (size_t)2 * cfg->corr_cap * 4 + (size_t)2 * hmax * 20 + 64
                            + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : FTL_HMAX) * 8      /* >= the HM of whichever instantiation launch() picks */ + (size_t)rays * 8
-                           + rects * 8 + 32);                 /* facing-edge list (u16 x 4 per rect) + edge counters */
+                           + rects * 8 + 32                   /* facing-edge list (u16 x 4 per rect) + edge counters */
+                           + (size_t)FTL_PAIR_CAP * 2 + 16);  /* candidate list of phase 3 */
     }
+    if (const char* pad = getenv("FTL_DEBUG_LDS_PAD_RAYS")) P.lds_rays += atoi(pad);      // diagnostic: occupancy of the ray kernel without touching the code
+    if (getenv("FTL_DEBUG_PRINT_LDS")) fprintf(stderr, "ftl: ray kernel LDS %d B per env\n", P.lds_rays);
     if (P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
     *out = h;
     return FTL_OK;

@@ -26,7 +26,12 @@
 #define FTL_WAVE 64
 #define FTL_HMAX 12         // compile-time cap on max_prev_obs (the shipped training configs use 10)
 #define FTL_MAX_RAYS 1024   // rays per env over all ray sensors (the host rejects more than 1023)
-#define FTL_WIDE_ARC 8      // segments facing more candidate rays than this are tested by the whole wavefront, one ray per lane
+#ifndef FTL_WIDE_ARC
+#define FTL_WIDE_ARC 3       // segments facing more candidate rays than this have their pairs written by the whole wavefront, one ray per lane
+#endif
+#define FTL_PAIR_CAP (64 * FTL_WIDE_ARC)     // entries of phase 3's candidate list (u16: lane of the segment << 10 | ray): one sensor's worth of a
+                                             // chunk at most.  Kept small on purpose: 512 bytes of LDS more cost the ray kernel a wavefront per CU
+                                             // and 6 % of its speed (FTL_DEBUG_LDS_PAD_RAYS)
 #ifndef FTL_RAYS_WPE
 #define FTL_RAYS_WPE 5      // 96 VGPRs; LDS (7 KB per env) caps the CU at ~22 waves, i.e. 5.5 per SIMD, and the kernel is bound by VALU issue
 #endif
@@ -423,6 +428,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     double2* s_ray = reinterpret_cast<double2*>(s_rmask + ((n_u32 + 3) & ~3));     // 16-byte aligned [total_rays]
     unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [total_rays][HM]
     double* s_miss = reinterpret_cast<double*>(s_best + (size_t)P.total_rays * HM);                     // [total_rays] |ray end - origin|
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_miss + P.total_rays);                  // [FTL_PAIR_CAP] candidate list of phase 3
     const unsigned long long kInfBits = 0x7fefffffffffffffull;                                       // DBL_MAX: "no hit"
 
     // Round trip 1: everything that is addressed by the env index alone is requested at once -- the scalars, every ring slot
@@ -633,6 +639,11 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 }
             };
             const float fdir_rad = (float)(fdir * kDeg2Rad);
+            // Few table entries face a ray at all and fewer face more than one (about 30 candidates in 45 entries per env-step on the
+            // bench workload, spread over the sensors): tested where they are found, each round keeps a handful of lanes busy.  The
+            // candidates of a chunk -- all sensors -- go to a list of (lane that holds the segment, ray) pairs instead; the list is
+            // tested densely, 64 pairs at a time, the segment coming from its lane by a cross-lane read.
+            int np_u = 0;                                  // entries in the list (wave-uniform)
             for (int w0 = 0; w0 < n_items; w0 += FTL_WAVE) {
                 const int w = w0 + lane;
                 int m = -1, mq = 0;
@@ -661,6 +672,18 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     dmin2 = __builtin_fmaf(nx, nx, ny * ny);
                 }
                 FTL_RTIC(4);
+                auto flush = [&](int np) {
+                    __syncthreads();                                     // the pairs are in LDS
+                    for (int p0 = 0; p0 < np; p0 += FTL_WAVE) {
+                        const int p = p0 + lane;
+                        const unsigned rec = p < np ? s_pair[p] : 0u;
+                        const int L = (int)(rec >> 10);
+                        const float4 sgp = make_float4(__shfl(sg.x, L), __shfl(sg.y, L), __shfl(sg.z, L), __shfl(sg.w, L));
+                        const unsigned smp = (unsigned)__shfl((int)sm, L);
+                        if (p < np) test((int)(rec & 1023u), sgp, smp);
+                    }
+                    __syncthreads();                                     // read before the next pairs overwrite them
+                };
 #pragma nounroll
                 for (int k = 0; k < c.n_lasers; k++) {
                     const FtlRaySensor rs = P.ray_sens[k];                 // wave-uniform: two scalar loads
@@ -691,27 +714,47 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     if (threadIdx.x == 0) { s_rcyc[8] += 1; }
                     { int mc = cnt; for (int o = 32; o >= 1; o >>= 1) mc = max(mc, __shfl_xor(mc, o)); int ni = __popcll(__ballot(m >= 0)); int sc = cnt; for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o); if (threadIdx.x == 0) { s_rcyc[9] += mc; s_rcyc[10] += sc; s_rcyc[11] += ni; s_rcyc[12] += (mc <= 2); s_rcyc[13] += (mc > 2 && mc <= 4); s_rcyc[14] += (mc > 4 && mc <= 8); s_rcyc[15] += (mc > 8); } }
 #endif
-                    // A segment next to the follower faces many rays (up to all N): one lane looping over them would hold the
-                    // whole wavefront for that many test iterations.  Such segments (rare: a few per cent of the chunks) are
-                    // handed to the wavefront instead -- broadcast the segment, one ray per lane.
+                    // (a) segments with more than FTL_WIDE_ARC candidates: the wavefront writes their pairs, one ray per lane; more than a
+                    //     wavefront of them (a segment next to the follower under a 180-ray sensor) are tested on the spot
                     unsigned long long wide = __ballot(cnt > FTL_WIDE_ARC);
                     while (wide) {
                         const int L = __ffsll((long long)wide) - 1; wide &= wide - 1;
-                        const float4 sgL = make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.x), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.y), L)),
-                                                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.z), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.w), L)));
-                        const unsigned smL = (unsigned)__builtin_amdgcn_readlane((int)sm, L);
                         const int i0L = __builtin_amdgcn_readlane(i0, L), cntL = __builtin_amdgcn_readlane(cnt, L);
-                        for (int t = lane; t < cntL; t += FTL_WAVE) {
-                            int i = i0L + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
-                            test(rbase + i, sgL, smL);
+                        if (cntL > FTL_WAVE) {
+                            const float4 sgL = make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.x), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.y), L)),
+                                                           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.z), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg.w), L)));
+                            const unsigned smL = (unsigned)__builtin_amdgcn_readlane((int)sm, L);
+                            for (int t = lane; t < cntL; t += FTL_WAVE) {
+                                int i = i0L + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
+                                test(rbase + i, sgL, smL);
+                            }
+                            continue;
                         }
+                        if (np_u + cntL > FTL_PAIR_CAP) { flush(np_u); np_u = 0; }
+                        if (lane < cntL) {
+                            int i = i0L + lane; i = i < 0 ? i + N : (i >= N ? i - N : i);
+                            s_pair[np_u + lane] = (unsigned short)((L << 10) | (rbase + i));
+                        }
+                        np_u += cntL;
                     }
+                    // (b) the others: each lane appends its own 0..FTL_WIDE_ARC pairs at the prefix sum of the counts (no atomics: the
+                    //     count is two bits, a ballot per bit gives every lane its offset and the wavefront the total)
                     const int own = cnt > FTL_WIDE_ARC ? 0 : cnt;
+                    int pre = 0, tot = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) if ((FTL_WIDE_ARC >> b) != 0) {
+                        const unsigned long long bm = __ballot((own >> b) & 1);
+                        pre += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u)) << b;
+                        tot += __popcll(bm) << b;
+                    }
+                    if (np_u + tot > FTL_PAIR_CAP) { flush(np_u); np_u = 0; }       // (tot <= 64 x FTL_WIDE_ARC = FTL_PAIR_CAP)
                     for (int t = 0; t < own; t++) {
                         int i = i0 + t; i = i < 0 ? i + N : (i >= N ? i - N : i);
-                        test(rbase + i, sg, sm);
+                        s_pair[np_u + pre + t] = (unsigned short)((lane << 10) | (rbase + i));
                     }
+                    np_u += tot;
                 }
+                if (np_u > 0) { flush(np_u); np_u = 0; }      // before the next chunk replaces the segments in the lanes
             }
         }
         FTL_RTIC(5);
