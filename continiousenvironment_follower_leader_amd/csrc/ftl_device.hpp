@@ -438,7 +438,6 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     const int* swp = P.snap_win + (size_t)env * hmax * 4;
     const int4* srp = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)env * hmax * nrect_dyn;
     const int swv = lane < hmax * 4 ? swp[lane] : 0;
-    const int4 dynq = lane < hmax * nrect_dyn ? srp[lane] : make_int4(0, 0, 0, 0);
     // per-env scalars come through VECTOR loads (one word per lane) and are made wave-uniform with readlane: streaming
     // them through the scalar cache (s_load) costs several microseconds per miss under this kernel's load
     const size_t fo = (size_t)env * P.R + 1;            // follower
@@ -457,13 +456,16 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     const int nsnap = snap_count < hmax ? snap_count : hmax;       // valid snapshots, newest = snap_count-1
     const unsigned all_snaps = (1u << nsnap) - 1u;                  // bit a = age a (nsnap <= hmax <= FTL_HMAX = 12)
     const int4* stp = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)scen * c.n_static;
-    const int4 stq = lane < c.n_static ? stp[lane] : make_int4(0, 0, 0, 0);     // static rect of this lane (round trip 2)
 
 #pragma nounroll
     for (int which = 0; which < 2; which++) {
         int n_sens = 0; float lmax = 0.0f;
         FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) { n_sens++; lmax = fmaxf(lmax, (float)c.lasers[k].length); }
         if (n_sens == 0) continue;
+        // this lane's snapshot rect and static rect: requested here, with the pass's other loads, and dead after phase 1 (held across
+        // the passes they cost the test loop of phase 3 eight registers)
+        const int4 dynq = lane < hmax * nrect_dyn ? srp[lane] : make_int4(0, 0, 0, 0);
+        const int4 stq = lane < c.n_static ? stp[lane] : make_int4(0, 0, 0, 0);
         if (!((scan_ok >> which) & 1)) {       // sensors.py:893/962: the reference raises UnboundLocalError here
             for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which && !(EXPL && c.lasers[k].compas)) {
                 const int Wd = c.lasers[k].count * (c.lasers[k].pad_sectors ? 4 : 1);
