@@ -189,21 +189,48 @@ __global__ void __launch_bounds__(FTL_WAVE) ftl_gz_kernel(const FtlGzParams P, c
             int slot = newest - a; slot += slot < 0 ? H : 0;
             const float4* sg = ring + (size_t)slot * P.max_seg;
             const int ns = a == 0 ? ((L.react_corridor ? 2 * (Cn - 1) : 0) + (L.react_green ? 2 : 0) + (L.react_obstacles ? max(n_pts - 1, 0) : 0)) : ring_n[slot];
-            for (int w = lane; w < ns * N; w += FTL_WAVE) {
-                const int si = w / N, ray = w - si * N;
+            // One segment per lane against its candidate rays only, as in phase 3 of ftl_rays_kernel: the rays whose direction lies inside
+            // the arc the segment subtends at the origin (the follower), widened by >= 0.01 rad (polynomial float32 atan2, error 2e-5 rad),
+            // are the only ones that can cross it; a segment through / next to the origin (within 1 % of the rays' length) or beyond the rays' reach keeps all / none.
+            const float fN = (float)N, inv_step = fN * 0.15915494309189535f, invN = 1.0f / fN;
+            const float phis = (float)((yaw - 45.0) * kDeg2Rad) * inv_step, slack = 0.02f + 0.01f * inv_step;
+            const float reach = (float)L.length * 1.01f, near2 = 1e-4f * reach * reach;     // (metres here, not pixels: relative margins)
+            for (int si = lane; si < ns; si += FTL_WAVE) {
                 const float4 q = sg[si];
-                const double2 e = s_ray[ray];
+                int i0 = 0, nc = N;                       // candidate rays i0 .. i0 + nc - 1 (mod N)
+                {
+                    const float ex_ = q.z - q.x, ey_ = q.w - q.y;
+                    const float l2 = __builtin_fmaf(ex_, ex_, ey_ * ey_);
+                    const float tt = l2 > 0.0f ? fminf(fmaxf(__fdividef(-__builtin_fmaf(q.x, ex_, q.y * ey_), l2), 0.0f), 1.0f) : 0.0f;
+                    const float nx = __builtin_fmaf(tt, ex_, q.x), ny = __builtin_fmaf(tt, ey_, q.y);
+                    const float dmin2 = __builtin_fmaf(nx, nx, ny * ny);
+                    if (dmin2 > reach * reach) continue;
+                    float uA = __builtin_fmaf(arc_atan2(q.y, q.x), inv_step, -phis), uB = __builtin_fmaf(arc_atan2(q.w, q.z), inv_step, -phis);
+                    uA = __builtin_fmaf(-floorf(uA * invN), fN, uA); uB = __builtin_fmaf(-floorf(uB * invN), fN, uB);
+                    float diff = uB - uA; if (diff < 0.0f) diff += fN;
+                    float start = uA, wd = diff;
+                    if (diff > 0.5f * fN) { start = uB; wd = fN - diff; }
+                    if (!(dmin2 < near2 || wd > 0.5f * fN - 0.05f)) {
+                        i0 = (int)ceilf(start - slack);
+                        nc = (int)floorf(start + wd + slack) - i0 + 1;
+                        nc = nc > N ? N : nc;
+                    }
+                }
                 const double ax = q.x, ay = q.y, bx = q.z, by = q.w;
                 const float bax = q.z - q.x, bay = q.w - q.y;
-                const bool t1 = (e.y - ay) * (0 - ax) > (0 - ay) * (e.x - ax);       // ccw(A,C,D), SEN:608-614 with C = [[0, 0]] (int)
-                const bool t2 = (e.y - by) * (0 - bx) > (0 - by) * (e.x - bx);       // ccw(B,C,D)
-                const bool t3 = (0 - ay) * (double)bax > (double)bay * (0 - ax);     // ccw(A,B,C)
-                const bool t4 = (e.y - ay) * (double)bax > (double)bay * (e.x - ax); // ccw(A,B,D)
-                if (!((t1 != t2) && (t3 != t4))) continue;
-                const double dapx = (double)(-bay), dapy = (double)bax;              // seg_intersect, SEN:626-640
-                const double t = (dapx * ax + dapy * ay) / (dapx * e.x + dapy * e.y);
-                const double x = t * e.x + 0, y = t * e.y + 0;
-                atomicMin(&s_best[ray * H + a], (unsigned long long)__double_as_longlong(x * x + y * y));
+                for (int t = 0; t < nc; t++) {
+                    int ray = i0 + t; ray = ray < 0 ? ray + N : (ray >= N ? ray - N : ray);
+                    const double2 e = s_ray[ray];
+                    const bool t1 = (e.y - ay) * (0 - ax) > (0 - ay) * (e.x - ax);       // ccw(A,C,D), SEN:608-614 with C = [[0, 0]] (int)
+                    const bool t2 = (e.y - by) * (0 - bx) > (0 - by) * (e.x - bx);       // ccw(B,C,D)
+                    const bool t3 = (0 - ay) * (double)bax > (double)bay * (0 - ax);     // ccw(A,B,C)
+                    const bool t4 = (e.y - ay) * (double)bax > (double)bay * (e.x - ax); // ccw(A,B,D)
+                    if (!((t1 != t2) && (t3 != t4))) continue;
+                    const double dapx = (double)(-bay), dapy = (double)bax;              // seg_intersect, SEN:626-640
+                    const double tq = (dapx * ax + dapy * ay) / (dapx * e.x + dapy * e.y);
+                    const double x = tq * e.x + 0, y = tq * e.y + 0;
+                    atomicMin(&s_best[ray * H + a], (unsigned long long)__double_as_longlong(x * x + y * y));
+                }
             }
         }
         __syncthreads();
