@@ -156,118 +156,118 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const Ft
         }
         __syncthreads();
         auto corr_pt = [&](int p) -> const double* { return staged ? s_c64 + 4 * (p - base) : corr_slot(P, env, p); };
-    for (int k = 0; k < c.n_lasers; k++) {
-        const ftl_laser_cfg& Lc = c.lasers[k];
-        if (!Lc.compas) continue;
-        const int N = Lc.count, H = Lc.history, W = 5 * N, which = Lc.after_tracker;
-        float* out = out_base + Lc.out_offset;
-        float* pol = (C.out.policy_obs && P.pol_off[k] >= 0) ? C.out.policy_obs + (size_t)env * P.pol_h * P.pol_width + P.pol_off[k] : nullptr;
-        const float flen = (float)Lc.length;
-        if (!((scan_ok >> which) & 1)) {      // SEN:1192/1244: the reference raises UnboundLocalError (error bit set by the tracker code)
-            for (int i = lane; i < H * W; i += FTL_WAVE) {
-                const float v = (i % W) < N ? flen : 0.0f;
-                out[i] = v;
-                if (pol) pol[(i / W) * P.pol_width + (i % W)] = fminf(fmaxf(v / flen, 0.0f), 1.0f);
+        for (int k = 0; k < c.n_lasers; k++) {
+            const ftl_laser_cfg& Lc = c.lasers[k];
+            if (!Lc.compas) continue;
+            const int N = Lc.count, H = Lc.history, W = 5 * N, which = Lc.after_tracker;
+            float* out = out_base + Lc.out_offset;
+            float* pol = (C.out.policy_obs && P.pol_off[k] >= 0) ? C.out.policy_obs + (size_t)env * P.pol_h * P.pol_width + P.pol_off[k] : nullptr;
+            const float flen = (float)Lc.length;
+            if (!((scan_ok >> which) & 1)) {      // SEN:1192/1244: the reference raises UnboundLocalError (error bit set by the tracker code)
+                for (int i = lane; i < H * W; i += FTL_WAVE) {
+                    const float v = (i % W) < N ? flen : 0.0f;
+                    out[i] = v;
+                    if (pol) pol[(i / W) * P.pol_width + (i % W)] = fminf(fmaxf(v / flen, 0.0f), 1.0f);
+                }
+                continue;
             }
-            continue;
-        }
-        double2* s_ray = reinterpret_cast<double2*>(scratch);                               // [N]
-        unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + N);      // [N][H]: squared distance, wall class in the 2 low bits
-        int* s_win = reinterpret_cast<int*>(s_best + N * H);                                // [H][2]
-        __syncthreads();
-        const int nsnap = snap_count < H ? snap_count : H;
-        if (lane < H) {
-            int lo = 0, hi = 0;
-            if (lane < nsnap) {
-                int slot = newest - lane; slot += slot < 0 ? P.hmax : 0;
-                lo = s_winall[4 * slot + 2 * which]; hi = s_winall[4 * slot + 2 * which + 1];
+            double2* s_ray = reinterpret_cast<double2*>(scratch);                               // [N]
+            unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + N);      // [N][H]: squared distance, wall class in the 2 low bits
+            int* s_win = reinterpret_cast<int*>(s_best + N * H);                                // [H][2]
+            __syncthreads();
+            const int nsnap = snap_count < H ? snap_count : H;
+            if (lane < H) {
+                int lo = 0, hi = 0;
+                if (lane < nsnap) {
+                    int slot = newest - lane; slot += slot < 0 ? P.hmax : 0;
+                    lo = s_winall[4 * slot + 2 * which]; hi = s_winall[4 * slot + 2 * which + 1];
+                }
+                s_win[2 * lane] = lo; s_win[2 * lane + 1] = hi;
             }
-            s_win[2 * lane] = lo; s_win[2 * lane + 1] = hi;
-        }
-        for (int i = lane; i < N; i += FTL_WAVE) {
-            double s, co;
-            sincos_bounded(((fdir + Lc.angle_offset) + i * (360.0 / (double)N)) * kDeg2Rad, s, co);
-            s_ray[i] = make_double2(cx + co * Lc.length, cy + s * Lc.length);
-        }
-        for (int i = lane; i < N * H; i += FTL_WAVE) s_best[i] = kInf;
-        __syncthreads();
-        int umin = 0x7fffffff, umax = 0;
-        for (int a = 0; a < nsnap; a++) { umin = min(umin, s_win[2 * a]); umax = max(umax, s_win[2 * a + 1]); }
-        const int n_wall = nsnap > 0 ? 2 * max(umax - umin - 1, 0) : 0;
-        const int n_items = n_wall + 2 * nsnap;
-        // one item per lane -- a wall shared by every snapshot whose window holds both of its points, or an end cap of ONE snapshot --
-        // against its candidate rays (the wall stays in registers; N <= 36)
-        for (int item = lane; item < n_items; item += FTL_WAVE) {
-            double ax, ay, bx, by; unsigned sm = 0; int cls;
-            if (item < n_wall) {
-                const int p = umin + (item >> 1), side = item & 1;             // side 0: right wall (class 3), 1: left wall (class 2)
-                for (int a = 0; a < nsnap; a++) if (s_win[2 * a] <= p && p + 1 < s_win[2 * a + 1]) sm |= 1u << a;
-                const double* u = corr_pt(p); const double* v = corr_pt(p + 1);
-                ax = u[2 * side]; ay = u[2 * side + 1]; bx = v[2 * side]; by = v[2 * side + 1];
-                cls = side ? 2 : 3;
-            } else {
-                const int a = (item - n_wall) >> 1, back = (item - n_wall) & 1;   // front = corridor[-1] (class 0), back = corridor[0] (class 1)
-                const double* u = corr_pt(back ? s_win[2 * a] : s_win[2 * a + 1] - 1);
-                ax = u[0]; ay = u[1]; bx = u[2]; by = u[3];
-                sm = 1u << a; cls = back;
+            for (int i = lane; i < N; i += FTL_WAVE) {
+                double s, co;
+                sincos_bounded(((fdir + Lc.angle_offset) + i * (360.0 / (double)N)) * kDeg2Rad, s, co);
+                s_ray[i] = make_double2(cx + co * Lc.length, cy + s * Lc.length);
             }
-            if (!sm) continue;
-            // Candidate rays, as in phase 3 of ftl_rays_kernel (float32 throughout: this only selects which rays get the reference's
-            // float64 test).  A wall whose closest approach is beyond the rays' reach (2 px of slack) cannot be hit; otherwise only the
-            // rays whose direction lies inside the arc the wall subtends at the follower (polynomial atan2, widened by >= 0.01 rad, two
-            // orders of magnitude above its error) can cross it -- typically 1-3 of the N.  A wall next to the follower keeps every ray.
-            int i0 = 0, cnt = N;
-            {
-                const float axf = (float)(ax - cx), ayf = (float)(ay - cy), bxf = (float)(bx - cx), byf = (float)(by - cy);
-                const float ux = bxf - axf, uy = byf - ayf, l2 = __builtin_fmaf(ux, ux, uy * uy);
-                const float tt = l2 > 0.0f ? fminf(fmaxf(__fdividef(-__builtin_fmaf(axf, ux, ayf * uy), l2), 0.0f), 1.0f) : 0.0f;
-                const float nx = __builtin_fmaf(tt, ux, axf), ny = __builtin_fmaf(tt, uy, ayf);
-                const float dmin2 = __builtin_fmaf(nx, nx, ny * ny), reach = flen + 2.0f;
-                if (dmin2 > reach * reach) continue;
-                const float fN = (float)N, inv_step = fN * 0.15915494309189535f;
-                const float phis = (float)((fdir + Lc.angle_offset) * kDeg2Rad) * inv_step;
-                float uA = __builtin_fmaf(arc_atan2(ayf, axf), inv_step, -phis), uB = __builtin_fmaf(arc_atan2(byf, bxf), inv_step, -phis);
-                const float invN = __fdividef(1.0f, fN);
-                uA = __builtin_fmaf(-floorf(uA * invN), fN, uA); uB = __builtin_fmaf(-floorf(uB * invN), fN, uB);   // into [0, N) (an ulp outside is absorbed by the wrap below)
-                float diff = uB - uA; if (diff < 0.0f) diff += fN;
-                float start = uA, wd = diff;
-                if (diff > 0.5f * fN) { start = uB; wd = fN - diff; }
-                if (!(dmin2 < 4.0f || wd > 0.5f * fN - 0.05f)) {
-                    const float slack = 0.02f + 0.01f * inv_step;
-                    i0 = (int)ceilf(start - slack);
-                    cnt = (int)floorf(start + wd + slack) - i0 + 1;
-                    cnt = cnt > N ? N : cnt;
+            for (int i = lane; i < N * H; i += FTL_WAVE) s_best[i] = kInf;
+            __syncthreads();
+            int umin = 0x7fffffff, umax = 0;
+            for (int a = 0; a < nsnap; a++) { umin = min(umin, s_win[2 * a]); umax = max(umax, s_win[2 * a + 1]); }
+            const int n_wall = nsnap > 0 ? 2 * max(umax - umin - 1, 0) : 0;
+            const int n_items = n_wall + 2 * nsnap;
+            // one item per lane -- a wall shared by every snapshot whose window holds both of its points, or an end cap of ONE snapshot --
+            // against its candidate rays (the wall stays in registers; N <= 36)
+            for (int item = lane; item < n_items; item += FTL_WAVE) {
+                double ax, ay, bx, by; unsigned sm = 0; int cls;
+                if (item < n_wall) {
+                    const int p = umin + (item >> 1), side = item & 1;             // side 0: right wall (class 3), 1: left wall (class 2)
+                    for (int a = 0; a < nsnap; a++) if (s_win[2 * a] <= p && p + 1 < s_win[2 * a + 1]) sm |= 1u << a;
+                    const double* u = corr_pt(p); const double* v = corr_pt(p + 1);
+                    ax = u[2 * side]; ay = u[2 * side + 1]; bx = v[2 * side]; by = v[2 * side + 1];
+                    cls = side ? 2 : 3;
+                } else {
+                    const int a = (item - n_wall) >> 1, back = (item - n_wall) & 1;   // front = corridor[-1] (class 0), back = corridor[0] (class 1)
+                    const double* u = corr_pt(back ? s_win[2 * a] : s_win[2 * a + 1] - 1);
+                    ax = u[0]; ay = u[1]; bx = u[2]; by = u[3];
+                    sm = 1u << a; cls = back;
+                }
+                if (!sm) continue;
+                // Candidate rays, as in phase 3 of ftl_rays_kernel (float32 throughout: this only selects which rays get the reference's
+                // float64 test).  A wall whose closest approach is beyond the rays' reach (2 px of slack) cannot be hit; otherwise only the
+                // rays whose direction lies inside the arc the wall subtends at the follower (polynomial atan2, widened by >= 0.01 rad, two
+                // orders of magnitude above its error) can cross it -- typically 1-3 of the N.  A wall next to the follower keeps every ray.
+                int i0 = 0, cnt = N;
+                {
+                    const float axf = (float)(ax - cx), ayf = (float)(ay - cy), bxf = (float)(bx - cx), byf = (float)(by - cy);
+                    const float ux = bxf - axf, uy = byf - ayf, l2 = __builtin_fmaf(ux, ux, uy * uy);
+                    const float tt = l2 > 0.0f ? fminf(fmaxf(__fdividef(-__builtin_fmaf(axf, ux, ayf * uy), l2), 0.0f), 1.0f) : 0.0f;
+                    const float nx = __builtin_fmaf(tt, ux, axf), ny = __builtin_fmaf(tt, uy, ayf);
+                    const float dmin2 = __builtin_fmaf(nx, nx, ny * ny), reach = flen + 2.0f;
+                    if (dmin2 > reach * reach) continue;
+                    const float fN = (float)N, inv_step = fN * 0.15915494309189535f;
+                    const float phis = (float)((fdir + Lc.angle_offset) * kDeg2Rad) * inv_step;
+                    float uA = __builtin_fmaf(arc_atan2(ayf, axf), inv_step, -phis), uB = __builtin_fmaf(arc_atan2(byf, bxf), inv_step, -phis);
+                    const float invN = __fdividef(1.0f, fN);
+                    uA = __builtin_fmaf(-floorf(uA * invN), fN, uA); uB = __builtin_fmaf(-floorf(uB * invN), fN, uB);   // into [0, N) (an ulp outside is absorbed by the wrap below)
+                    float diff = uB - uA; if (diff < 0.0f) diff += fN;
+                    float start = uA, wd = diff;
+                    if (diff > 0.5f * fN) { start = uB; wd = fN - diff; }
+                    if (!(dmin2 < 4.0f || wd > 0.5f * fN - 0.05f)) {
+                        const float slack = 0.02f + 0.01f * inv_step;
+                        i0 = (int)ceilf(start - slack);
+                        cnt = (int)floorf(start + wd + slack) - i0 + 1;
+                        cnt = cnt > N ? N : cnt;
+                    }
+                }
+                for (int t = 0; t < cnt; t++) {
+                    int ray = i0 + t; ray = ray < 0 ? ray + N : (ray >= N ? ray - N : ray);
+                    const double2 e = s_ray[ray];
+                    double d2;
+                    if (wall_hit(ax, ay, bx, by, cx, cy, e.x, e.y, d2)) {
+                        // np.argmin takes the FIRST of equal minima in the order front, back, left walls, right walls (SEN:1166): the class code
+                        // rides in the two low mantissa bits, so equal distances resolve the same way (3 ulp of float64 before the float32 store)
+                        const unsigned long long key = ((unsigned long long)__double_as_longlong(d2) & ~3ull) | (unsigned long long)cls;
+                        for (int a = 0; a < nsnap; a++) if ((sm >> a) & 1u) atomicMin(&s_best[ray * H + a], key);
+                    }
                 }
             }
-            for (int t = 0; t < cnt; t++) {
-                int ray = i0 + t; ray = ray < 0 ? ray + N : (ray >= N ? ray - N : ray);
+            __syncthreads();
+            // rows, oldest first (SEN:1247): block 0 = rays without a wall hit (|end - position|), then front / back / left / right
+            for (int i = lane; i < H * W; i += FTL_WAVE) { out[i] = 0.0f; if (pol) pol[(i / W) * P.pol_width + (i % W)] = 0.0f; }
+            __syncthreads();
+            for (int w = lane; w < N * H; w += FTL_WAVE) {
+                const int ray = w / H, a = w - ray * H;
+                const unsigned long long key = s_best[w];
                 const double2 e = s_ray[ray];
-                double d2;
-                if (wall_hit(ax, ay, bx, by, cx, cy, e.x, e.y, d2)) {
-                    // np.argmin takes the FIRST of equal minima in the order front, back, left walls, right walls (SEN:1166): the class code
-                    // rides in the two low mantissa bits, so equal distances resolve the same way (3 ulp of float64 before the float32 store)
-                    const unsigned long long key = ((unsigned long long)__double_as_longlong(d2) & ~3ull) | (unsigned long long)cls;
-                    for (int a = 0; a < nsnap; a++) if ((sm >> a) & 1u) atomicMin(&s_best[ray * H + a], key);
-                }
+                int col; double v;
+                if (a < nsnap && key != kInf) { col = (1 + (int)(key & 3ull)) * N + ray; v = sqrt(__longlong_as_double((long long)(key & ~3ull))); }
+                else { const double qx = e.x - cx, qy = e.y - cy; col = ray; v = sqrt(__builtin_fma(qy, qy, qx * qx)); }
+                const float vf = (float)v;
+                out[(H - 1 - a) * W + col] = vf;
+                if (pol) pol[(H - 1 - a) * P.pol_width + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
             }
+            __syncthreads();
         }
-        __syncthreads();
-        // rows, oldest first (SEN:1247): block 0 = rays without a wall hit (|end - position|), then front / back / left / right
-        for (int i = lane; i < H * W; i += FTL_WAVE) { out[i] = 0.0f; if (pol) pol[(i / W) * P.pol_width + (i % W)] = 0.0f; }
-        __syncthreads();
-        for (int w = lane; w < N * H; w += FTL_WAVE) {
-            const int ray = w / H, a = w - ray * H;
-            const unsigned long long key = s_best[w];
-            const double2 e = s_ray[ray];
-            int col; double v;
-            if (a < nsnap && key != kInf) { col = (1 + (int)(key & 3ull)) * N + ray; v = sqrt(__longlong_as_double((long long)(key & ~3ull))); }
-            else { const double qx = e.x - cx, qy = e.y - cy; col = ray; v = sqrt(__builtin_fma(qy, qy, qx * qx)); }
-            const float vf = (float)v;
-            out[(H - 1 - a) * W + col] = vf;
-            if (pol) pol[(H - 1 - a) * P.pol_width + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
-        }
-        __syncthreads();
-    }
     }
 
     // ---------------- LaserSensor / LeaderTrackDetector_* --------------------------------------------------------------------------
