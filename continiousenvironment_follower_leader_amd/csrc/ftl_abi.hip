@@ -484,6 +484,13 @@ int ftl_episode_metrics(ftl_handle* h, double* dev_metrics, int32_t* dev_errors,
 
 #include "ftl_gazebo.hpp"      // follower-relative tracker / ray sensors (include/ftl_gazebo.h), same translation unit
 
+#ifdef FTL_WAVE_TIMES
+extern "C" int ftl_debug_wave_timeline(unsigned long long* times, unsigned int* info) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(times, HIP_SYMBOL(ftl::g_wt), sizeof(unsigned long long) * 2 * 8192) != hipSuccess ||
+           hipMemcpyFromSymbol(info, HIP_SYMBOL(ftl::g_wi), sizeof(unsigned int) * 8192) != hipSuccess;
+}
+#endif
 #ifdef FTL_PROFILE_PATHS
 extern "C" int ftl_debug_wave_times(unsigned long long* out) {
     hipDeviceSynchronize();

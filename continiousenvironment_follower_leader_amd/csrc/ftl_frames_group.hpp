@@ -81,6 +81,11 @@ template <int G> __device__ __forceinline__ void group_argmin(float& v, int& idx
     }
 }
 
+#ifdef FTL_WAVE_TIMES
+// diagnostic build only (profiles/tools/wave_timeline.py): start / end of every frame-kernel wavefront of the last launch, nothing else
+__device__ unsigned long long g_wt[2 * 8192];      // [wave][start, end] in 100 MHz ticks (s_memrealtime)
+__device__ unsigned int g_wi[8192];                // [wave] bit 0: an env was reset, bits 8..: trajectory searches of its envs
+#endif
 #ifdef FTL_PROFILE_PATHS
 // diagnostic build only (profiles/tools/path_counts.py): how often each branch of the frame is taken
 __device__ unsigned long long g_prof[16];
@@ -125,6 +130,9 @@ struct GCtx {
     int scen, cur_target_id, leader_finished, done, crash, is_in_box, is_on_trace, too_close;
     int step_count, finish_timer, traj_len, trk_counter, corr_lo, corr_hi, seed_end, snap_count;
     int error, episodes, green_count, green_len, scan_ok, route_len, near_cnt, snap_head, hint, green_tiny, resets, acc_consumed;
+#ifdef FTL_WAVE_TIMES
+    int dbg_walk, dbg_full;   // diagnostic: exact green walks / whole-trajectory searches of this step
+#endif
     int err_acc;         // error bits of episodes that ended inside this launch (g_reset clears `error`): OR-ed into FTL_EI_ERROR_STICKY
     int n_search;        // frames of this step in which this env needed a trajectory search (regrouping key only)
     int fps;             // frames of this step: cfg.frames_per_step, or the env's last draw under random_frames_per_step
@@ -611,6 +619,9 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
 #ifdef FTL_DEBUG_EXACT
         if (exact) { int why = (E.green_len != nn - 1) ? 1 : (E.green_count < 1 ? 2 : 3); E.error = (E.error & 0xff) | (why << 8) | ((((E.error >> 16) + 1) & 0xffff) << 16); }
 #endif
+#ifdef FTL_WAVE_TIMES
+        if (exact) E.dbg_walk += 1;
+#endif
 #ifndef FTL_ABLATE_EXACT
         if (exact) Gn = g_green_walk<G>(P, E, W, tiny);
 #endif
@@ -727,6 +738,9 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             else if (wbest < eps2_lo) { E.is_on_trace = 1; E.is_in_box = 0; E.hint = widx; E.hx = wp.x; E.hy = wp.y; }   // some point is within epsilon
             else {                                             // closest point of the whole trajectory (ENV:1924-1930)
                 float ab2; int ai; float2 q2; float skip2;
+#ifdef FTL_WAVE_TIMES
+                E.dbg_full += 1;
+#endif
                 g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, widx, wbest, wp, ab2, ai, q2, skip2);
                 E.clr_a = sqrtf(fmaxf(fminf(ab2, skip2), 0.0f)) * 0.999999f - 1e-3f;  // every trajectory point is at least this far
                 if (ai != 0x7fffffff) {
@@ -1137,6 +1151,10 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     int* s_cnt = reinterpret_cast<int*>(lds + (size_t)EPW * P.cfg.n_static * 16);
     E.scan_ok = 0; E.near_cnt = 0; E.n_search = 0; E.err_acc = 0;
     const Limits L = lane_limits(P.cfg, E.r);
+#ifdef FTL_WAVE_TIMES
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_wt[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    bool wt_reset = false; E.dbg_walk = 0; E.dbg_full = 0;
+#endif
 #ifdef FTL_PROFILE_PATHS
     if (threadIdx.x < 16) s_cyc[threadIdx.x] = 0;
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_wave_t[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -1209,6 +1227,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
 #ifdef FTL_PROFILE_PATHS
             if (threadIdx.x == 0) s_cyc[12] = 1;
 #endif
+#ifdef FTL_WAVE_TIMES
+            wt_reset = true;
+#endif
             if (go) { E.episodes += 1; E.err_acc |= E.error; }
             g_reset<G>(P, E, go ? (E.scen + P.n_envs) % P.scen.n_scenarios : E.scen, go);
             __syncthreads();
@@ -1249,6 +1270,13 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         if (E.r == 0) P.keys[E.env] = (uint8_t)key;
     }
     FTL_TIC(10);
+#ifdef FTL_WAVE_TIMES
+    {
+        int ns = (E.valid && E.r == 0) ? E.n_search : 0, nw = (E.valid && E.r == 0) ? E.dbg_walk : 0, nf = (E.valid && E.r == 0) ? E.dbg_full : 0;
+        for (int o = 32; o >= 1; o >>= 1) { ns += __shfl_xor(ns, o); nw += __shfl_xor(nw, o); nf += __shfl_xor(nf, o); }
+        if (threadIdx.x == 0 && blockIdx.x < 8192) { g_wt[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); g_wi[blockIdx.x] = (wt_reset ? 1u : 0u) | ((unsigned)min(ns, 255) << 8) | ((unsigned)min(nw, 255) << 16) | ((unsigned)min(nf, 255) << 24); }
+    }
+#endif
 #ifdef FTL_PROFILE_PATHS
     __syncthreads();
     if (threadIdx.x < 16) atomicAdd(&g_cyc[threadIdx.x], s_cyc[threadIdx.x]);
