@@ -464,7 +464,12 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         if (n_sens == 0) continue;
         // this lane's snapshot rect and static rect: requested here, with the pass's other loads, and dead after phase 1 (held across
         // the passes they cost the test loop of phase 3 eight registers)
-        const int4 dynq = lane < hmax * nrect_dyn ? srp[lane] : make_int4(0, 0, 0, 0);
+        // (with room for both in one wavefront -- 37 + 10 lanes on the bench workload -- the snapshot rects sit in the lanes behind the
+        //  static ones and phase 1 pushes both with ONE pass of its rect code)
+        const int ndyn = hmax * nrect_dyn;
+        const bool merged = c.n_static + ndyn <= FTL_WAVE;
+        const int dl = merged ? lane - c.n_static : lane;                   // index of this lane's snapshot rect
+        const int4 dynq = (dl >= 0 && dl < ndyn) ? srp[dl] : make_int4(0, 0, 0, 0);
         const int4 stq = lane < c.n_static ? stp[lane] : make_int4(0, 0, 0, 0);
         if (!((scan_ok >> which) & 1)) {       // sensors.py:893/962: the reference raises UnboundLocalError here
             for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].after_tracker == which && !(EXPL && c.lasers[k].compas)) {
@@ -534,13 +539,19 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
             s_green[at] = make_float4(ax, ay, bx, by); s_gmask[at] = sm;
         };
         {
-            push_rect(SEG_STATIC, stq, lane < c.n_static ? all_snaps : 0u);     // identical in every snapshot
-            for (int w = lane + FTL_WAVE; w < c.n_static; w += FTL_WAVE) push_rect(SEG_STATIC, stp[w], all_snaps);
-            {   // snapshot rects: lane = ring slot * nrect_dyn + object; the leader (object 0) is a static-class object (it
-                // sits in game_object_list), bears are the dynamic class.  (1..5 objects per snapshot: a reciprocal instead of a division)
-                const int slot = (int)(((unsigned)lane * P.inv_nrect_dyn) >> 16), o = lane - slot * nrect_dyn;
-                int a = newest - slot; a += a < 0 ? hmax : 0;
-                push_rect(o == 0 ? SEG_STATIC : SEG_DYNAMIC, dynq, (lane < hmax * nrect_dyn && a < nsnap) ? 1u << a : 0u);
+            // snapshot rects: index = ring slot * nrect_dyn + object; the leader (object 0) is a static-class object (it sits in
+            // game_object_list), bears are the dynamic class.  (1..5 objects per snapshot: a reciprocal instead of a division)
+            const int dls = dl < 0 ? 0 : dl;
+            const int slot = (int)(((unsigned)dls * P.inv_nrect_dyn) >> 16), o = dls - slot * nrect_dyn;
+            int a = newest - slot; a += a < 0 ? hmax : 0;
+            const unsigned sm_dyn = (dl >= 0 && dl < ndyn && a < nsnap) ? 1u << a : 0u;
+            if (merged) {
+                const bool is_st = lane < c.n_static;                      // static rects are identical in every snapshot
+                push_rect((is_st || o == 0) ? SEG_STATIC : SEG_DYNAMIC, is_st ? stq : dynq, is_st ? all_snaps : sm_dyn);
+            } else {
+                push_rect(SEG_STATIC, stq, lane < c.n_static ? all_snaps : 0u);
+                for (int w = lane + FTL_WAVE; w < c.n_static; w += FTL_WAVE) push_rect(SEG_STATIC, stp[w], all_snaps);
+                push_rect(o == 0 ? SEG_STATIC : SEG_DYNAMIC, dynq, sm_dyn);
             }
             // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
             for (int p = umin + lane; p < umax - 1; p += FTL_WAVE) {
