@@ -456,10 +456,19 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
     if corr_cap:
         c.corr_cap = pow2(corr_cap)       # the tracker rings are indexed with a mask
     elif c.has_tracker:
-        # points are >= tracker_saving_period/2 steps of leader motion apart once the leader runs at full speed;
-        # seeded points are period*5*v apart.  4x head-room, overflow is detected (FTL_ERR_CORR_OVERFLOW).
-        seed_gap = c.tracker_saving_period * 5 * l_max
-        c.corr_cap = pow2(max(32, int(4 * c.corridor_length / max(seed_gap, 1e-9))))
+        # The corridor is trimmed by LENGTH (corridor_length), so its point count is length / spacing.  A point is saved every
+        # tracker_saving_period scans = period/2 steps = period/2 * frames_per_step frames of leader motion (two scans per step);
+        # seeded points are period*5*v apart.  A leader that always runs at its full speed gets 2.5x head-room on that count.  Speed /
+        # acceleration regimes can slow it down without a bound (a multiplier drawn from [0, 0.5]): those configs keep the flat 4x
+        # over the seeded spacing that the soak runs have been through.  Overflow is detected (FTL_ERR_CORR_OVERFLOW), never silent.
+        # The ray kernel keeps a float32 copy of the ring in LDS, where 1.5 KB decide about a wavefront per SIMD: hence
+        # no flat 4x for everybody.
+        if c.n_speed_regime >= 0 or c.n_acc_regime >= 0:
+            c.corr_cap = pow2(max(32, int(4 * c.corridor_length / max(c.tracker_saving_period * 5 * l_max, 1e-9))))
+        else:
+            fps_min = c.rand_fps_lo if c.rand_fps_hi > 0 else c.frames_per_step
+            gap = c.tracker_saving_period * min(5.0, fps_min / 2.0) * l_max
+            c.corr_cap = pow2(max(32, int(2.5 * c.corridor_length / max(gap, 1e-9))))
     else:
         c.corr_cap = 16
     c.route_cap = int(route_cap)
