@@ -492,6 +492,12 @@ extern "C" int ftl_debug_wave_timeline(unsigned long long* times, unsigned int* 
 }
 #endif
 #ifdef FTL_PROFILE_PATHS
+extern "C" int ftl_debug_heavy(unsigned long long* out, int clear) {      // [17] section cycles of the long wavefronts + their number
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ftl::g_cyc_heavy), sizeof(unsigned long long) * 17) != hipSuccess) return 1;
+    if (clear) { unsigned long long z[17] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ftl::g_cyc_heavy), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
 extern "C" int ftl_debug_wave_times(unsigned long long* out) {
     hipDeviceSynchronize();
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ftl::g_wave_t), sizeof(unsigned long long) * 2 * 8192) != hipSuccess;

@@ -95,6 +95,7 @@ __device__ unsigned long long g_prof[16];
 #define FTL_PROF(slot, cond, n) do { if (cond) atomicAdd(&g_prof[slot], (unsigned long long)(n)); } while (0)
 #endif
 __device__ unsigned long long g_cyc[16];
+__device__ unsigned long long g_cyc_heavy[17];     // the same sections over the wavefronts that ran longer than 115 us; [16] = their number
 __device__ unsigned long long g_wave_t[2 * 8192];    // [wave][start, end] in 100 MHz ticks (s_memrealtime), last launch
 __device__ unsigned int g_whist[2][64];             // wave lifetime histogram (bins of 4096 cycles), [did a reset]
 __shared__ unsigned long long s_cyc[16];           // per-wave accumulators, flushed once at the end of the kernel
@@ -1281,6 +1282,12 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     __syncthreads();
     if (threadIdx.x < 16) atomicAdd(&g_cyc[threadIdx.x], s_cyc[threadIdx.x]);
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_wave_t[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), t0 = blockIdx.x < 8192 ? g_wave_t[2 * blockIdx.x] : t1;
+        const bool heavy = __builtin_amdgcn_readfirstlane((int)(t1 - t0)) > 11500;       // 100 MHz ticks
+        if (heavy && threadIdx.x < 16) atomicAdd(&g_cyc_heavy[threadIdx.x], s_cyc[threadIdx.x]);
+        if (heavy && threadIdx.x == 0) atomicAdd(&g_cyc_heavy[16], 1ull);
+    }
     if (threadIdx.x == 0 && C.mode != 1) {
         unsigned long long tot = 0; for (int i = 0; i < 11; i++) if (i != 9) tot += s_cyc[i];
         int bin = (int)(tot >> 12); bin = bin > 63 ? 63 : bin;
