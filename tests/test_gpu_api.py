@@ -108,9 +108,11 @@ def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
 
 def test_regrouping_never_changes_a_result(monkeypatch):
     """The slot -> env permutation (envs of similar expected cost share a wavefront) is rebuilt every other launch; with
-    it switched off (FTL_NO_REGROUP=1 at ftl_create) every output and every state field must be bit-identical."""
+    it switched off (FTL_NO_REGROUP=1 at ftl_create; =0 forces it on at any batch size) every output and every state field must be
+    bit-identical."""
     n = 4096 + 37                      # not a multiple of the regroup block or of the envs per wavefront
     cfg = _pool_cfg(max_steps=300, warm_start=10)
+    monkeypatch.setenv("FTL_NO_REGROUP", "0")      # (by default the sort is on only when the frame kernel needs more than one round of wavefronts)
     a = _vec(n, cfg)
     monkeypatch.setenv("FTL_NO_REGROUP", "1")
     b = _vec(n, cfg)

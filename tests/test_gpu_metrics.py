@@ -84,9 +84,10 @@ def test_metrics_sum_is_order_independent_and_reproducible():
     import os
     n = 8192 + 11
     cfg = _pool_cfg(max_steps=150, warm_start=10)
-    a = _vec(n, cfg)
-    os.environ["FTL_NO_REGROUP"] = "1"
     try:
+        os.environ["FTL_NO_REGROUP"] = "0"          # forced on (the default switches it on beyond one round of wavefronts only)
+        a = _vec(n, cfg)
+        os.environ["FTL_NO_REGROUP"] = "1"
         b = _vec(n, cfg)
     finally:
         del os.environ["FTL_NO_REGROUP"]

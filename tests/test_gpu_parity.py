@@ -118,9 +118,11 @@ def _pool_scenarios(limit):
 
 
 @pytest.mark.parametrize("n_envs,steps,policy", [(512, 60, "random"), (256, 120, "mixed")])
-def test_hip_matches_oracle_batch(n_envs, steps, policy):
-    """Seeded batch of config-B envs from the scenario pool: every output of every env and step against the oracle."""
+def test_hip_matches_oracle_batch(n_envs, steps, policy, monkeypatch):
+    """Seeded batch of config-B envs from the scenario pool: every output of every env and step against the oracle.  (The cost sort of
+    the envs is forced on: by default a batch this small runs unsorted.)"""
     import json
+    monkeypatch.setenv("FTL_NO_REGROUP", "0")
     from oracle import OracleEnv
     from golden_util import config_for
     meta = json.loads(str(np.load(GOLDEN + "/pool_B.npz")["meta"]))
