@@ -111,7 +111,7 @@ def build_workload(name, n, rank, seed, device):
         text = ("config B: %d envs/GPU, 35 rocks + 2 walls + 1 dynamic obstacle, tracker_v2 + LeaderCorridor_Prev_lasers_v2 x2 "
                 "(12 rays all edges L=100, 24 rays obstacles L=150, H=5), 10 frames/step, auto-reset from a %d-scenario pool "
                 "captured from the reference's reset()")
-        return cfg, pool, text, 4096, ("ftl_frames_group_kernel<4, false>", "ftl_rays_kernel<5, false, false>")     # 4,010 B by the formula, the survey's rounded figure
+        return cfg, pool, text, 4096, ("ftl_frames_group_kernel<4, false>", "ftl_rays_kernel<5, false, false, false>")     # 4,010 B by the formula, the survey's rounded figure
     ep = {"D": "D_s2_chase", "E": "E_s3_chase", "F": "F_s7_chase", "C": "C_s1_chase", "L": "L_s2_chase", "T": "T_s3_chase"}[name]
     _, m = load_episode(ep)
     cfg = config_for(m, scen_route_len=256, env_id_base=base, rng_seed=seed)
@@ -120,12 +120,12 @@ def build_workload(name, n, rank, seed, device):
     if name == "D":
         text = ("config D: %d envs/GPU, 100 rocks + 2 walls + 1 dynamic obstacle, tracker_v2 + one LeaderCorridor_Prev_lasers_v2 with 180 rays "
                 "(obstacles only, L=200, H=5; the LaserPrevSensor replacement), 10 frames/step, auto-reset from a %d-scenario pool built by the host generator")
-        return cfg, pool, text, bytes_per_env_step(cfg, 161, 32), ("ftl_frames_group_kernel<4, false>", "ftl_rays_kernel<5, false, false>")
+        return cfg, pool, text, bytes_per_env_step(cfg, 161, 32), ("ftl_frames_group_kernel<4, false>", "ftl_rays_kernel<5, false, false, false>")
     if name == "E":
         text = ("config E (hardcore, ENV:2015-2105 with manual_control=False): %d envs/GPU, 20 rocks + 2 walls + 2 dynamic obstacles, sensors of B, "
                 "5 frames/step, leader speed + acceleration regimes on per-env counter streams, early stopping, auto-reset from a %d-scenario "
                 "pool built by the host generator")
-        return cfg, pool, text, bytes_per_env_step(cfg, 330, 103), ("ftl_frames_group_kernel<4, true>", "ftl_rays_kernel<5, false, false>")
+        return cfg, pool, text, bytes_per_env_step(cfg, 330, 103), ("ftl_frames_group_kernel<4, true>", "ftl_rays_kernel<5, false, false, true>")
     if name in ("C", "L", "T"):
         what = {"C": "tracker_v2 + Prev_lasers_v2 (12 rays) + two LeaderCorridor_lasers_compas (12 and 20 rays, H=5)",
                 "L": "tracker_v2 + two LaserSensor lidars (37 x 20 and 13 x 10 marching points) + three leader-track detectors + Prev_lasers_v2 (12 rays)",
@@ -133,11 +133,11 @@ def build_workload(name, n, rank, seed, device):
         text = "config " + name + " (row f3): %d envs/GPU, config B's world (" + ("2" if name == "L" else "1") + " dynamic obstacle) with " + what + \
                ", 10 frames/step, auto-reset from a %d-scenario pool built by the host generator"
         bpe = bytes_per_env_step(cfg, 161, 32) + 4 * sum(a.out_len for a in cfg.aux)
-        kn = ("ftl_frames_group_kernel<4, %s>" % ("false"), "ftl_rays_kernel<5, true, false> + ftl_aux_kernel" + (" + ftl_tracker1_kernel" if name == "T" else ""))
+        kn = ("ftl_frames_group_kernel<4, %s>" % ("false"), "ftl_rays_kernel<5, true, false, %s> + ftl_aux_kernel" % ("true" if name == "T" else "false") + (" + ftl_tracker1_kernel" if name == "T" else ""))
         return cfg, pool, text, bpe, kn
     text = ("config F (server/config/3c1bc): %d envs/GPU, 20 rocks + 2 walls + 2 dynamic obstacles, same sensors with H=10, "
             "random 30-70 frames/step, random leader speed regimes, auto-reset from a %d-scenario pool built by the host generator")
-    return cfg, pool, text, bytes_per_env_step(cfg, 330, 103), ("ftl_frames_group_kernel<4, true>", "ftl_rays_kernel<10, false, true>")
+    return cfg, pool, text, bytes_per_env_step(cfg, 330, 103), ("ftl_frames_group_kernel<4, true>", "ftl_rays_kernel<10, false, true, true>")
 
 
 def main():

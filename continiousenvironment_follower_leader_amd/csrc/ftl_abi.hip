@@ -223,7 +223,11 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     {   // corridor ring (f32x4) + near rects (int4 + u32) + corridor refs (u32) + green caps (f32x4 + u32) + counters
         // + ray ends (double2) + per-(ray, snapshot) minima (u64 x HM) + miss readings (f64)
         const size_t rects = (size_t)cfg->n_static + hmax + (size_t)hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
-        P.lds_rays = (int)((size_t)cfg->corr_cap * 16 + rects * 20 + (size_t)2 * cfg->corr_cap * 4 + (size_t)2 * hmax * 20 + 64
+        // LDS copy of the corridor ring: up to 128 points (the windows of the snapshots span a few dozen; the ring itself is sized
+        // for a crawling leader); FTL_DEBUG_CORR_LDS_CAP forces a smaller copy (tests of the unstaged path)
+        P.corr_lds_cap = cfg->corr_cap < 128 ? cfg->corr_cap : 128;
+        if (const char* lc = getenv("FTL_DEBUG_CORR_LDS_CAP")) { int v = atoi(lc); if (v >= 2 && v <= cfg->corr_cap && (v & (v - 1)) == 0) P.corr_lds_cap = v; }
+        P.lds_rays = (int)((size_t)P.corr_lds_cap * 16 + rects * 20 + (size_t)2 * P.corr_lds_cap * 4 + (size_t)2 * hmax * 20 + 64
                            + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : FTL_HMAX) * 8      /* >= the HM of whichever instantiation launch() picks */ + (size_t)rays * 8
                            + rects * 8 + 32                   /* facing-edge list (u16 x 4 per rect) + edge counters */
                            + (size_t)FTL_PAIR_CAP * 2 + 16);  /* candidate list of phase 3 */
@@ -371,17 +375,24 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
             bool expl = false;
             for (int k = 0; k < h->P.cfg.n_lasers; k++) expl = expl || h->P.cfg.lasers[k].explicit_angles != 0 || h->P.cfg.lasers[k].pad_sectors != 0 || h->P.cfg.lasers[k].compas != 0;
             const dim3 rgrid(count);
+            // CAPPED: the LDS copy of the corridor ring is smaller than the ring (corr_cap > 128, the configs with regimes or the v1 tracker):
+            // the instantiations that carry the unstaged path
+#define FTL_LAUNCH_RAYS(HM_, EXPL_, SPLIT_) do { \
+                if (capped) hipLaunchKernelGGL((ftl_rays_kernel<HM_, EXPL_, SPLIT_, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2); \
+                else hipLaunchKernelGGL((ftl_rays_kernel<HM_, EXPL_, SPLIT_, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2); } while (0)
+            const bool capped = h->P.corr_lds_cap < h->P.cfg.corr_cap;
             if (parts > 1) {   // two-stream mode: the instantiations that map blocks to one half of the slot groups
-                if (!expl && h->P.hmax > 5 && h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-                else if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, true, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-                else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, true, true>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+                if (!expl && h->P.hmax > 5 && h->P.hmax <= 10) FTL_LAUNCH_RAYS(10, false, true);
+                else if (h->P.hmax <= 5) FTL_LAUNCH_RAYS(5, true, true);
+                else FTL_LAUNCH_RAYS(FTL_HMAX, true, true);
             } else if (expl) {        // LeaderCorridor_lasers or pad_sectors somewhere in the config: the two instantiations that carry that code
-                if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, true, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-                else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, true, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-            } else if (h->P.hmax <= 5) hipLaunchKernelGGL((ftl_rays_kernel<5, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-            else if (h->P.hmax <= 8) hipLaunchKernelGGL((ftl_rays_kernel<8, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
-            else if (h->P.hmax <= 10) hipLaunchKernelGGL((ftl_rays_kernel<10, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);   // the shipped training configs
-            else hipLaunchKernelGGL((ftl_rays_kernel<FTL_HMAX, false, false>), rgrid, block, h->P.lds_rays, s, h->dP, c2);
+                if (h->P.hmax <= 5) FTL_LAUNCH_RAYS(5, true, false);
+                else FTL_LAUNCH_RAYS(FTL_HMAX, true, false);
+            } else if (h->P.hmax <= 5) FTL_LAUNCH_RAYS(5, false, false);
+            else if (h->P.hmax <= 8) FTL_LAUNCH_RAYS(8, false, false);
+            else if (h->P.hmax <= 10) FTL_LAUNCH_RAYS(10, false, false);   // the shipped training configs
+            else FTL_LAUNCH_RAYS(FTL_HMAX, false, false);
+#undef FTL_LAUNCH_RAYS
         }
         if (tev) (void)hipEventRecord(tev[2], s);
     };

@@ -48,6 +48,7 @@ struct FtlRaySensor {
 struct FtlDevParams {
     ftl_config cfg;
     int32_t n_envs, R, lasers_len, total_rays, hmax, lds_rays;
+    int32_t corr_lds_cap;             // corridor points the ray kernel stages in LDS (a power of two <= cfg.corr_cap; a longer window is read in place)
     int32_t pol_off[FTL_MAX_LASERS], pol_width, pol_h;   // fused sensorPrev output: column offset per sensor (-1: not part of it), row width, common history
     // per-env state (views into the caller-owned state buffer), all [n_envs][...]
     float* rb_pos; double* rb_dbl; int32_t* rb_int; int32_t* env_int; double* env_dbl;
@@ -385,7 +386,8 @@ __shared__ unsigned long long s_rcyc[16];
 #define FTL_FOR_LASERS(k) _Pragma("unroll") for (int k = 0; k < FTL_MAX_LASERS; k++) if (k < c.n_lasers && !(EXPL && c.lasers[k].compas))
 
 // SPLIT = the launch covers one of the interleaved halves of the slot groups (two-stream mode) instead of all envs
-template <int HM, bool EXPL = false, bool SPLIT = false>
+// CAPPED = the LDS copy of the corridor ring is smaller than the ring itself: a window that does not fit is read in place (below)
+template <int HM, bool EXPL = false, bool SPLIT = false, bool CAPPED = false>
 __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const FtlDevParams* __restrict__ Pp, const FtlCall C) {
     extern __shared__ __align__(16) unsigned char lds[];
     using namespace ftl;
@@ -409,14 +411,14 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     FTL_RTIC_INIT;
     const int hmax = P.hmax;
     const int nrect_dyn = P.R - 1;      // leader + bears per snapshot
-    const int cmask = c.corr_cap - 1;   // corr_cap is a power of two (validated on the host)
+    const int cmask = P.corr_lds_cap - 1;   // LDS copy of the corridor ring: a power of two of slots, a window of consecutive points maps 1:1
     // LDS: f32 corridor ring | near rects (int4 + mask; static class first region, dynamic class second) | corridor
     //      segment references (u32) | green caps (f32x4 + mask) | class counters | ray ends | minima.
     // Rect edges and corridor segments are expanded on the fly in phase 3, so the table stays small (occupancy).
     const int cap_rs = c.n_static + hmax, cap_rd = hmax * (P.R - 2 > 0 ? P.R - 2 : 0) + 1;
-    const int cap_cr = 2 * c.corr_cap, cap_gr = 2 * hmax;
+    const int cap_cr = 2 * P.corr_lds_cap, cap_gr = 2 * hmax;
     float4* s_corr = reinterpret_cast<float4*>(lds);
-    int4* s_rect = reinterpret_cast<int4*>(s_corr + c.corr_cap);                 // [cap_rs + cap_rd]
+    int4* s_rect = reinterpret_cast<int4*>(s_corr + P.corr_lds_cap);             // [cap_rs + cap_rd]
     float4* s_green = reinterpret_cast<float4*>(s_rect + cap_rs + cap_rd);       // [cap_gr]
     unsigned* s_rmask = reinterpret_cast<unsigned*>(s_green + cap_gr);           // [cap_rs + cap_rd]
     unsigned* s_cref = s_rmask + cap_rs + cap_rd;                                // [cap_cr]: p & cmask | side << 15 | mask << 16
@@ -500,10 +502,13 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
 #endif
         __syncthreads();
         if (lane < SEG_CLASSES + 2) s_cnt[lane] = 0;
-        for (int p = umin + lane; p < umax; p += FTL_WAVE) {
-            const double* q = corr_slot(P, env, p);
-            s_corr[p & cmask] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
-        }
+        // The windows of the snapshots span a few dozen corridor points; the tracker's ring is sized for the worst case (a leader that
+        // crawls under a speed regime: 256 points), and LDS of that size would cost this kernel a third of its wavefronts.  The LDS copy
+        // holds P.corr_lds_cap points; a longer span (rare) is not staged -- phase 3 then reads its corridor segments from the ring in
+        // global memory, uncompacted (same values, same results).
+        const bool staged = !CAPPED || umax - umin <= P.corr_lds_cap;
+        auto corr_f32 = [&](int p) { const double* q = corr_slot(P, env, p); return make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]); };
+        if (staged) for (int p = umin + lane; p < umax; p += FTL_WAVE) s_corr[p & cmask] = corr_f32(p);
         __syncthreads();
         FTL_RTIC(0);
 #if defined(FTL_RAYS_STOP) && FTL_RAYS_STOP == 1
@@ -554,7 +559,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 push_rect(o == 0 ? SEG_STATIC : SEG_DYNAMIC, dynq, sm_dyn);
             }
             // corridor polylines: segment p -> p+1 belongs to every snapshot whose window holds both points
-            for (int p = umin + lane; p < umax - 1; p += FTL_WAVE) {
+            if (staged) for (int p = umin + lane; p < umax - 1; p += FTL_WAVE) {
                 unsigned sm = 0;
 #pragma unroll
                 for (int a = 0; a < HM; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
@@ -564,11 +569,12 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     push_corr(p, 1, u.z, u.w, v.z, v.w, sm);      // left border
                 }
             }
+            else if (lane == 0) s_cnt[SEG_CORRIDOR] = 2 * max(umax - umin - 1, 0);      // every segment of the span, culled where it is fetched
             if (lane < nsnap) {     // green-zone end caps of snapshot age `lane` (sensors.py:648-650)
                 int lo = 0, hi = 0;
 #pragma unroll
                 for (int j = 0; j < HM; j++) if (j == lane) { lo = win_lo[j]; hi = win_hi[j]; }
-                float4 u = s_corr[lo & cmask], v = s_corr[(hi - 1) & cmask];
+                float4 u = staged ? s_corr[lo & cmask] : corr_f32(lo), v = staged ? s_corr[(hi - 1) & cmask] : corr_f32(hi - 1);
                 push_green(u.x, u.y, u.z, u.w, 1u << lane);
                 push_green(v.x, v.y, v.z, v.w, 1u << lane);
             }
@@ -635,10 +641,19 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                     const int e = ent & 3;
                     sg = e == 0 ? make_float4(l, b, r, b) : e == 1 ? make_float4(r, t, r, b) : e == 2 ? make_float4(r, t, l, t) : make_float4(l, b, l, t);
                 } else if (mq == SEG_CORRIDOR) {             // polyline segment p -> p+1 of the right (0) / left (1) border
-                    const unsigned ref = s_cref[m];
-                    const int p = ref & 0x7fff; sm = ref >> 16;
-                    const float4 u = s_corr[p], v = s_corr[(p + 1) & cmask];
-                    sg = (ref >> 15) & 1u ? make_float4(u.z, u.w, v.z, v.w) : make_float4(u.x, u.y, v.x, v.y);
+                    if (staged) {
+                        const unsigned ref = s_cref[m];
+                        const int p = ref & 0x7fff; sm = ref >> 16;
+                        const float4 u = s_corr[p], v = s_corr[(p + 1) & cmask];
+                        sg = (ref >> 15) & 1u ? make_float4(u.z, u.w, v.z, v.w) : make_float4(u.x, u.y, v.x, v.y);
+                    } else {                                 // span too long for the LDS copy: segment m of the span, straight from the ring
+                        const int p = umin + (m >> 1);
+                        sm = 0;
+#pragma unroll
+                        for (int a = 0; a < HM; a++) if (a < nsnap && win_lo[a] <= p && p + 1 < win_hi[a]) sm |= 1u << a;
+                        const float4 u = corr_f32(p), v = corr_f32(p + 1);
+                        sg = (m & 1) ? make_float4(u.z, u.w, v.z, v.w) : make_float4(u.x, u.y, v.x, v.y);
+                    }
                 } else { sg = s_green[m]; sm = s_gmask[m]; }
             };
             // the reference's intersection test of ray `ray` (index into s_ray / s_best) with segment sgx
@@ -675,6 +690,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 float angA = 0.0f, angB = 0.0f, dmin2 = 3.0e38f;
                 if (m >= 0) {
                     fetch(mq, m, sg, sm);
+                    if (sm == 0u) m = -1;                    // (unstaged corridor spans list every segment: one outside all windows faces no ray)
+                }
+                if (m >= 0) {
                     const float ax = sg.x - cx, ay = sg.y - cy, bx = sg.z - cx, by = sg.w - cy;
                     angA = arc_atan2(ay, ax); angB = arc_atan2(by, bx);
                     // closest approach of the segment to the follower (culling only: 2 px of slack in the records' reach)

@@ -186,6 +186,29 @@ def test_config_E_matches_oracle_batch_1024_envs():
     env.close()
 
 
+def test_unstaged_corridor_window_matches_oracle(monkeypatch):
+    """The ray kernel keeps a float32 copy of at most 128 corridor points in LDS; a longer window of the snapshots (a leader crawling
+    under a speed regime) is read from the tracker's ring in place.  FTL_DEBUG_CORR_LDS_CAP=8 makes every window too long: config E,
+    300 envs x 45 steps against the oracle through that path."""
+    n, steps = 300, 45
+    cfg, pool = _cfg_pool("E_s3_chase", 512, rng_seed=9, env_id_base=9000)
+    monkeypatch.setenv("FTL_DEBUG_CORR_LDS_CAP", "8")
+    env = _vec(n, cfg, pool)
+    monkeypatch.delenv("FTL_DEBUG_CORR_LDS_CAP")
+    scen = pool_scenarios(pool)
+    idx = (np.arange(n) * 5) % pool.n
+    env.reset(torch.from_numpy(idx.astype(np.int32)))
+    ora = OracleBatch(cfg, n, env_id_base=9000)
+    ora.reset(scen, idx)
+    _compare_with_oracle(env, ora, cfg, ("unstaged", "reset"))
+    for t in range(steps):
+        a = _actions(cfg, n, t, "mixed" if t % 2 else "random", seed=21)
+        env.step(torch.tensor(a, dtype=torch.float64, device="cuda:0"))
+        ora.step(a)
+        _compare_with_oracle(env, ora, cfg, ("unstaged", t))
+    env.close()
+
+
 # ---- the two-stream split path (ftl_abi.hip launch(): FTL_SPLIT, rays kernels <*, *, true>) ----------------------------------
 def _two(monkeypatch, n, cfg, pool, **kw):
     monkeypatch.setenv("FTL_SPLIT", "1")
