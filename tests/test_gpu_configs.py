@@ -45,6 +45,40 @@ def _actions(cfg, n, t, policy="random", seed=0):
     return np.stack([v, w], 1)
 
 
+def _corner_grazes(env, cfg, bad):
+    """(env, column) mask of the mismatching ray readings that are knife edges: the ray passes EXACTLY through a corner of an
+    axis-aligned rect (a static one, or a robot's hitbox now or in one of the snapshots).  Whether the reference's strict `ccw`
+    inequalities (SEN:608-614) count that as a hit depends on the last bit of cos / sin of the ray's direction -- numpy's, glibc's
+    and the device's differ there.  It is not a measure-zero event: reset() puts the follower on an exact
+    diagonal of the leader (x - y an integer) and the rects sit on a 5-px lattice, so a 45-degree ray meets lattice corners."""
+    out = np.zeros_like(bad)
+    pos = env.state_field("rb_pos").cpu().numpy().reshape(env.n, cfg.n_robots, 2)[:, 1].astype(np.float64)
+    fdir = env.state_field("rb_dbl").cpu().numpy().reshape(env.n, cfg.n_robots, abi.RD_COUNT)[:, 1, abi.RD_DIRECTION]
+    ei = env.state_field("env_int").cpu().numpy()
+    ri = env.state_field("rb_int").cpu().numpy().reshape(env.n, cfg.n_robots, abi.RI_COUNT)[:, :, :4]
+    sr = env.state_field("snap_rects").cpu().numpy().reshape(env.n, -1, 4)
+    st = env.pool.t["static_rects"].cpu().numpy() if hasattr(env, "pool") and env.pool is not None else None
+    for e, col in np.argwhere(bad):
+        for k in range(cfg.c.n_lasers):
+            l = cfg.c.lasers[k]
+            w = l.count * (5 if l.compas else (4 if l.pad_sectors else 1))
+            if not (l.out_offset <= col < l.out_offset + l.history * w) or l.compas:
+                continue
+            i = (col - l.out_offset) % w % l.count
+            ang = np.radians(fdir[e] + (l.ray_angles[i % 8] if l.explicit_angles else l.angle_offset + i * 360.0 / l.count))
+            d = np.array([np.cos(ang), np.sin(ang)])
+            rects = [ri[e].reshape(-1, 4), sr[e]]
+            if st is not None:
+                rects.append(st[ei[e, abi.EI_SCEN]])
+            r = np.concatenate(rects).astype(np.float64)
+            cx = np.concatenate([r[:, 0], r[:, 0] + r[:, 2], r[:, 0], r[:, 0] + r[:, 2]]) - pos[e, 0]
+            cy = np.concatenate([r[:, 1], r[:, 1], r[:, 1] + r[:, 3], r[:, 1] + r[:, 3]]) - pos[e, 1]
+            along = cx * d[0] + cy * d[1]; across = np.abs(cx * d[1] - cy * d[0])
+            if np.any((across < 1e-6) & (along > 0) & (along < l.length + 1)):
+                out[e, col] = True
+    return out
+
+
 def _compare_with_oracle(env, ora, cfg, tag):
     num = env.obs_num.cpu().numpy(); las = env.lasers.cpu().numpy()
     assert np.array_equal(env.done.cpu().numpy(), ora.done), (tag, "done")
@@ -54,6 +88,8 @@ def _compare_with_oracle(env, ora, cfg, tag):
     assert np.array_equal(env.target.cpu().numpy(), ora.target), (tag, "target")
     L = cfg.lasers_len
     bad = ~close(las[:, :L], ora.lasers[:, :L])
+    if bad.any():
+        bad &= ~_corner_grazes(env, cfg, bad)
     assert not bad.any(), (tag, "lasers", np.argwhere(bad)[:5], np.abs(las[:, :L] - ora.lasers[:, :L]).max())
     ri = env.state_field("rb_int").cpu().numpy().reshape(env.n, cfg.n_robots, abi.RI_COUNT)
     assert np.array_equal(ri[:, :, :6], ora.robot_ints()), (tag, "hitboxes")
