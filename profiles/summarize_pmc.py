@@ -12,7 +12,13 @@ import sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 n_envs = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 out = collections.defaultdict(dict)
-for f in sorted(glob.glob(root + "/pmc*/*/*_counter_collection.csv")):
+import os
+files = {}
+for f in glob.glob(root + "/pmc*/*/*_counter_collection.csv"):      # one file per pass: the newest, should a directory hold several runs
+    k = f.split("/pmc")[-1].split("/")[0]
+    if k not in files or os.path.getmtime(f) > os.path.getmtime(files[k]):
+        files[k] = f
+for f in sorted(files.values()):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "ftl_" not in r["Kernel_Name"]:
