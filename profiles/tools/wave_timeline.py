@@ -1,15 +1,15 @@
-"""Diagnostic (build with -DFTL_WAVE_TIMES, FTL_LIB=that .so): start / end of every frame-kernel wavefront of one launch of the bench
-workload in its steady state -- how the 4,096 wavefronts pack onto the 2,048 slots.  Not part of the product or the tests."""
+"""Diagnostic (build with -DFTL_WAVE_TIMES, FTL_LIB=that .so): start / end of every frame-kernel wavefront of one launch of a bench
+workload (FTL_TIMELINE_WORKLOAD, default B) in its steady state -- how the wavefronts pack onto the 2,048 slots.  Not part of the product or the tests."""
 import ctypes as C, json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 from golden_util import GOLDEN, config_for
 from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
 import bench
-z = np.load(GOLDEN + "/pool_B.npz"); meta = json.loads(str(z["meta"]))
-cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=int(z["route_len"].max()))
-n = 65536
-env = VecGame(n, device="cuda:0", config=cfg); pool = ScenarioPool.from_npz(cfg, GOLDEN + "/pool_B.npz", "cuda:0"); env.load_scenarios(pool)
+W = os.environ.get("FTL_TIMELINE_WORKLOAD", "B")
+n = bench.DEFAULT_ENVS[W]
+cfg, pool, *_ = bench.build_workload(W, n, 0, 0, torch.device("cuda:0"))
+env = VecGame(n, device="cuda:0", config=cfg); env.load_scenarios(pool)
 env.reset((torch.arange(n) % pool.n).to(torch.int32))
 acts = bench.make_actions(cfg, n, 16, 0, torch.device("cuda:0"))
 for k in range(320): env.step(acts[k % 16], auto_reset=True)
@@ -17,14 +17,18 @@ T = (C.c_ulonglong * (2 * 8192))(); I = (C.c_uint * 8192)()
 for rep in range(3):
     env.step(acts[rep], auto_reset=True)
     env.lib.ftl_debug_wave_timeline(T, I)
-    t = np.array(list(T), dtype=np.int64).reshape(8192, 2)[:n // 16]; info = np.array(list(I), dtype=np.int64)[:n // 16]
+    nw = (n + 15) // 16 if cfg.n_robots <= 4 else (n + 7) // 8
+    t = np.array(list(T), dtype=np.int64).reshape(8192, 2)[:nw]; info = np.array(list(I), dtype=np.int64)[:nw]
     t0 = t[:, 0].min(); st = (t[:, 0] - t0) / 100.0; en = (t[:, 1] - t0) / 100.0; d = en - st
     rs = (info & 1) == 1; ns = (info >> 8) & 255; nw = (info >> 16) & 255; nf = (info >> 24) & 255
     print("launch %d: kernel %.1f us; wave lifetime mean %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f; sum/2048 slots = %.1f us" % (
         rep, en.max(), d.mean(), *np.percentile(d, [10, 50, 90, 99]), d.max(), d.sum() / 2048))
     first = st < 5.0
-    print("  first round: %d waves, lifetime mean %.1f (ends p50 %.1f p90 %.1f max %.1f); second round: %d waves, lifetime mean %.1f, start p10 %.1f p50 %.1f p90 %.1f" % (
-        first.sum(), d[first].mean(), *np.percentile(en[first], [50, 90]), en[first].max(), (~first).sum(), d[~first].mean(), *np.percentile(st[~first], [10, 50, 90])))
+    if (~first).any():
+        print("  first round: %d waves, lifetime mean %.1f (ends p50 %.1f p90 %.1f max %.1f); second round: %d waves, lifetime mean %.1f, start p10 %.1f p50 %.1f p90 %.1f" % (
+            first.sum(), d[first].mean(), *np.percentile(en[first], [50, 90]), en[first].max(), (~first).sum(), d[~first].mean(), *np.percentile(st[~first], [10, 50, 90])))
+    else:
+        print("  one round: every wavefront starts within 5 us")
     print("  waves with a reset: %d, lifetime mean %.1f vs %.1f without; searches per wave mean %.1f; lifetime by searches: %s" % (
         rs.sum(), d[rs].mean() if rs.any() else 0, d[~rs].mean(), ns.mean(),
         " ".join("%d:%.0f(%d)" % (k, d[ns == k].mean(), (ns == k).sum()) for k in range(0, 40, 4) if (ns == k).any())))
