@@ -220,6 +220,7 @@ __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
 template <int G>
 __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen, bool go) {
     const ftl_config& c = P.cfg;
+    int init_n0 = 0; const float2* init_src = nullptr; float2* init_dst = nullptr;
     if (go) {
         E.scen = scen;
         int rr = (E.r < P.R) ? E.r : 0;
@@ -233,18 +234,8 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         int n0 = P.scen.init_traj_len[scen];              // initial leader_factual_trajectory (ENV:533-539)
         const float2* src = reinterpret_cast<const float2*>(P.scen.init_traj) + (size_t)scen * c.init_traj_cap;
         float2* dst = reinterpret_cast<float2*>(P.traj + (size_t)E.env * c.traj_cap * 2);
-        for (int k = E.r; k < n0; k += G) dst[k] = src[k];
         E.traj_len = n0;
-        // bounding boxes of the blocks of FTL_TRAJ_BLOCK consecutive points (search acceleration, see g_range_argmin)
-        float4* bb = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK);
-        for (int b = E.r; b * FTL_TRAJ_BLOCK < n0; b += G) {
-            float4 box = make_float4(3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f);
-            for (int k = b * FTL_TRAJ_BLOCK; k < n0 && k < (b + 1) * FTL_TRAJ_BLOCK; k++) {
-                float2 q = src[k];
-                box.x = fminf(box.x, q.x); box.y = fminf(box.y, q.y); box.z = fmaxf(box.z, q.x); box.w = fmaxf(box.w, q.y);
-            }
-            bb[b] = box;
-        }
+        init_n0 = n0; init_src = src; init_dst = dst;       // copied below, block by block, by the whole group
         E.step_count = 0; E.acc_penalty = 0; E.overall_reward = 0;
         E.done = 0; E.crash = 0; E.is_in_box = 0; E.is_on_trace = 0; E.too_close = 0;
         E.cur_target_id = 1; E.leader_finished = 0; E.finish_timer = -1;
@@ -256,6 +247,36 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         E.cur_mult = 1.0; E.cur_acc = 0.0; E.cum_speed = 0.0; E.resets += 1;      // ENV:449, 591-592; acc_consumed persists (ENV:1170)
     }
     // group-uniform from here on (go is the same in every lane of a group), so the broadcasts are safe
+    if (go) {
+        // The initial trajectory, one block of FTL_TRAJ_BLOCK points at a time: every lane loads its 32 / G points (all loads in flight
+        // before the first store -- a load / store loop of possibly aliasing pointers pays one memory round trip per point, 20 us per
+        // reset), stores them, and the block's bounding box (search acceleration, see g_range_argmin) comes from the same registers by a
+        // min / max over the group.
+        float4* bb = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK);
+        for (int b = 0; b * FTL_TRAJ_BLOCK < init_n0; b++) {
+            float2 q[FTL_TRAJ_BLOCK / G];
+#pragma unroll
+            for (int t = 0; t < FTL_TRAJ_BLOCK / G; t++) {
+                const int k = b * FTL_TRAJ_BLOCK + t * G + E.r;
+                q[t] = init_src[k < init_n0 ? k : init_n0 - 1];
+            }
+            float4 box = make_float4(3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f);
+#pragma unroll
+            for (int t = 0; t < FTL_TRAJ_BLOCK / G; t++) {
+                const int k = b * FTL_TRAJ_BLOCK + t * G + E.r;
+                if (k < init_n0) {
+                    init_dst[k] = q[t];
+                    box.x = fminf(box.x, q[t].x); box.y = fminf(box.y, q[t].y); box.z = fmaxf(box.z, q[t].x); box.w = fmaxf(box.w, q[t].y);
+                }
+            }
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) {
+                box.x = fminf(box.x, gx(box.x, off, G)); box.y = fminf(box.y, gx(box.y, off, G));
+                box.z = fmaxf(box.z, gx(box.z, off, G)); box.w = fmaxf(box.w, gx(box.w, off, G));
+            }
+            if (E.r == 0) bb[b] = box;
+        }
+    }
     float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py);
     if (go) {
         const double* rt = P.scen.route + (size_t)scen * c.route_cap * 2;
