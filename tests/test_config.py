@@ -87,6 +87,26 @@ def test_shipped_training_config_is_accepted():
         make_config(random_frames_per_step=[30, 70], frames_per_step=None)
 
 
+def test_corridor_ring_capacity_follows_the_point_spacing():
+    """corr_cap (the tracker rings, and through them the LDS footprint of the ray kernel): 2.5x the corridor's point count at full
+    leader speed -- a point every saving_period / 2 steps of frames_per_step frames --, the flat 4x over the seeded spacing when
+    regimes can slow the leader down, always a power of two, never below the corridor's point count."""
+    import warnings
+    _, mb = load_episode("B_s5_random")
+    _, me = load_episode("E_s3_chase")
+    b = config_for(mb).c
+    assert b.corr_cap == 64 and b.frames_per_step == 10
+    per_point = b.tracker_saving_period / 2 * b.frames_per_step * b.leader.max_speed        # px between saved points at full speed
+    assert b.corr_cap >= 2.5 * b.corridor_length / per_point > b.corr_cap / 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert config_for(me).c.corr_cap == 256                                             # speed + acceleration regimes
+        kw = dict(mb["kwargs"])
+        assert make_config(**dict(kw, frames_per_step=5)).c.corr_cap == 128                 # points twice as dense
+        assert make_config(**dict(kw, frames_per_step=3)).c.corr_cap == 256
+        assert make_config(**dict(kw, corr_cap=100)).c.corr_cap == 128                      # an explicit value is rounded up to a power of two
+
+
 def test_unknown_kwargs_are_swallowed_like_the_reference():
     make_config(some_future_flag=1)        # ENV:104 **kwargs
 
