@@ -403,6 +403,9 @@ __device__ __forceinline__ int g_closest(const float2* tr, int r, float px, floa
 // "no candidate" (idx == 0x7fffffff) or a result with d2 > thr2 means the reference's arg-min is beyond the threshold
 // too -- which is all the callers need (they compare the arg-min's distance with a threshold <= sqrt(thr2)).
 // `reversed`: the reference enumerates the range from hi-1 down to lo (the green list), ties go to the HIGHER index.
+#ifndef FTL_BOX_UNROLL
+#define FTL_BOX_UNROLL 2
+#endif
 template <int G>
 __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* bb, int r, float px, float py, int lo, int hi,
                                                float thr2, bool reversed, int init, float init_d2, float2 init_p, float& best, int& bi, float2& bp, float& skipmin) {
@@ -415,14 +418,23 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
         bound = fminf(bound, init_d2);                         // it bounds the minimum
     }
     const int b_lo = lo / FTL_TRAJ_BLOCK, b_hi = (hi - 1) / FTL_TRAJ_BLOCK;
-    for (int b0 = b_lo; b0 <= b_hi; b0 += G) {                // group-uniform trip count
-        int b = b0 + r;
-        float bd2 = __int_as_float(0x7f800000);
-        if (b <= b_hi) {
-            float4 box = bb[b];
-            float dx = fmaxf(fmaxf(box.x - px, px - box.z), 0.0f), dy = fmaxf(fmaxf(box.y - py, py - box.w), 0.0f);
-            bd2 = dx * dx + dy * dy - 1e-2f;                  // slack far above the float32 rounding of the box test
+    // The boxes are walked FTL_BOX_UNROLL x G at a time.  Their loads carry no guard (the index is clamped, the result masked), so they
+    // are issued back to back and arrive together: a whole-trajectory search (20-35 boxes) walks them in two memory round trips.
+    for (int b00 = b_lo; b00 <= b_hi; b00 += FTL_BOX_UNROLL * G) {      // group-uniform trip count
+        float4 bx[FTL_BOX_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FTL_BOX_UNROLL; u++) bx[u] = bb[min(b00 + u * G + r, b_hi)];
+        float bd2u[FTL_BOX_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FTL_BOX_UNROLL; u++) {
+            const float dx = fmaxf(fmaxf(bx[u].x - px, px - bx[u].z), 0.0f), dy = fmaxf(fmaxf(bx[u].y - py, py - bx[u].w), 0.0f);
+            bd2u[u] = (b00 + u * G + r <= b_hi) ? dx * dx + dy * dy - 1e-2f : __int_as_float(0x7f800000);   // slack far above the float32 rounding of the box test
         }
+#pragma unroll
+        for (int u = 0; u < FTL_BOX_UNROLL; u++) {
+        const int b0 = b00 + u * G;
+        const float bd2 = bd2u[u];
+        if (b0 > b_hi) break;                                     // group-uniform
         unsigned m = (unsigned)((__ballot(bd2 <= bound) >> (threadIdx.x & ~(G - 1))) & ((1ull << G) - 1ull));
         if (!(bd2 <= bound)) skipmin = fminf(skipmin, bd2);   // per lane; combined over the group at the end
         while (m) {                                           // group-uniform: every lane of the group sees the same mask
@@ -431,18 +443,24 @@ __device__ __forceinline__ void g_range_argmin(const float2* tr, const float4* b
             if (!(kd2 <= bound)) { skipmin = fminf(skipmin, kd2); continue; }   // the bound may have tightened since the mask was formed
             int s0 = (b0 + k) * FTL_TRAJ_BLOCK;
             int i0 = max(s0, lo), i1 = min(s0 + FTL_TRAJ_BLOCK, hi);
-#pragma unroll 8
-            for (int i = i0 + r; i < i1; i += G) {
-                float2 q = tr[i];
-                float ddx = q.x - px, ddy = q.y - py;
-                float d2 = ddx * ddx + ddy * ddy;
-                int ky = reversed ? (hi - 1 - i) : i;
-                if (d2 < best || (d2 == best && ky < key)) { best = d2; bi = i; key = ky; bp = q; }
+            float2 qq[FTL_TRAJ_BLOCK / G];
+#pragma unroll
+            for (int t = 0; t < FTL_TRAJ_BLOCK / G; t++) qq[t] = tr[min(i0 + r + t * G, i1 - 1)];      // unguarded, in flight together
+#pragma unroll
+            for (int t = 0; t < FTL_TRAJ_BLOCK / G; t++) {
+                const int i = i0 + r + t * G;
+                if (i < i1) {
+                    float ddx = qq[t].x - px, ddy = qq[t].y - py;
+                    float d2 = ddx * ddx + ddy * ddy;
+                    int ky = reversed ? (hi - 1 - i) : i;
+                    if (d2 < best || (d2 == best && ky < key)) { best = d2; bi = i; key = ky; bp = qq[t]; }
+                }
             }
             float gbest = best;                               // tighten the bound with what the group has seen so far
 #pragma unroll
             for (int off = G / 2; off >= 1; off >>= 1) gbest = fminf(gbest, gx(gbest, off, G));
             bound = fminf(bound, gbest);
+        }
         }
     }
     // combine the lanes: smallest d2, then earliest in the reference's enumeration order
@@ -705,11 +723,14 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         const float ahead2 = fmaxf((float)eps * 0.99999f - reach_a, 0.0f) * fmaxf((float)eps * 0.99999f - reach_a, 0.0f);
         {
             int w0 = E.hint - G; w0 = w0 < 0 ? 0 : w0;                       // a quarter of the window behind the old point, the rest ahead
+            float2 wq[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) wq[k] = tr[min(w0 + k * G + r, n - 1)];        // unguarded loads: issued back to back
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int i = w0 + k * G + r;
                 if (i < n) {
-                    float2 p = tr[i];
+                    float2 p = wq[k];
                     float dx = p.x - fpx, dy = p.y - fpy;
                     float d2 = dx * dx + dy * dy;
                     if (d2 < wbest) { wbest = d2; widx = i; wp = p; }
