@@ -382,6 +382,45 @@ __device__ __forceinline__ int g_green_walk(const FtlDevParams& P, const GCtx& E
     return Gc;
 }
 
+// The same walk by the WHOLE wavefront for one env (tr, n wave-uniform): 64 segments per pass, an inclusive scan over the wavefront.
+// One env's walk costs ~3 passes instead of ~10 group passes -- and the other fifteen envs of the wavefront used to wait through those.
+// Exactness as above: while no tiny segment is involved every partial sum is exact, whatever the order of the additions.
+struct WalkRes { int Gc; double wlen; int tiny; };
+__device__ __forceinline__ WalkRes w_green_walk(const float2* tr, int n, double maxd) {
+    const int lane = threadIdx.x & (FTL_WAVE - 1), cnt = n - 1;          // elements i = 0..cnt-1 <-> points (n-2-i, n-1-i)
+    double base = 0.0, wmax = 0.0; int Gc = 0; bool near = false, small = false;
+    for (int i0 = 0; i0 < cnt; i0 += FTL_WAVE) {
+        const int i = i0 + lane, ic = i < cnt ? i : cnt - 1;
+        const float2 cur = tr[n - 2 - ic], prev = tr[n - 1 - ic];
+        const bool v = i < cnt;
+        const double d = v ? euclid_f32(prev.x, prev.y, cur.x, cur.y) : 0.0;
+        double incl = d;
+#pragma unroll
+        for (int off = 1; off < FTL_WAVE; off <<= 1) {
+            const double o = __hiloint2double(__shfl_up(__double2hiint(incl), off), __shfl_up(__double2loint(incl), off));
+            if (lane >= off) incl += o;
+        }
+        const double val = base + incl;
+        near |= v && (fabs(val - maxd) < 1e-6);
+        small |= v && d != 0.0 && d < kTinySeg;
+        const unsigned long long in = __ballot(v && val <= maxd);          // a prefix of the lanes: the sums do not decrease
+        const int k = __popcll(in);
+        if (k > 0) wmax = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(val), k - 1), __builtin_amdgcn_readlane(__double2loint(val), k - 1));
+        Gc += k;
+        base += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(incl), FTL_WAVE - 1), __builtin_amdgcn_readlane(__double2loint(incl), FTL_WAVE - 1));
+        if (!(base <= maxd)) break;
+    }
+    WalkRes r;
+    r.tiny = (__ballot(small) != 0ull) || maxd > 500.0;
+    if (r.tiny && __ballot(near) != 0ull) {
+        Gc = g_green_seq(tr, n, maxd);
+        wmax = 0.0;
+        for (int i = 0; i < Gc; i++) { float2 cur = tr[n - 2 - i], prev = tr[n - 1 - i]; wmax += euclid_f32(prev.x, prev.y, cur.x, cur.y); }
+    }
+    r.Gc = Gc; r.wlen = wmax;
+    return r;
+}
+
 // first-index arg-min of the f32 squared distance to (px,py) over `n` trajectory points, point i = tr[base + i*stride]
 template <int G>
 __device__ __forceinline__ int g_closest(const float2* tr, int r, float px, float py, int base, int stride, int n) {
@@ -620,7 +659,9 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     // green zone (ENV:968-969): recomputed when a point was appended
     const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)E.env * c.traj_cap * 2);
 #ifndef FTL_ABLATE_GREEN
+    bool g_upd = false, g_walk = false; int Gn = 0; double W = 0.0; int tiny = 0;
     if (E.green_len != E.traj_len) {
+        g_upd = true;
         // One point was appended since the window was last derived.  The window (ENV:1828-1843: newest segments whose
         // sequential f64 length sum stays <= max_distance) is slid instead of re-walked: add the new segment, drop the
         // oldest ones while the running length exceeds max_distance.  The running length differs from the reference's
@@ -629,7 +670,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         const int nn = E.traj_len;
         const double maxd = c.max_distance;
         bool exact = (E.green_len != nn - 1) || (nn % 1024 == 0) || E.green_count < 1;
-        int Gn = E.green_count + 1; double W = E.green_w; int tiny = E.green_tiny;
+        Gn = E.green_count + 1; W = E.green_w; tiny = E.green_tiny;
         const double band = tiny ? 1e-6 : 0.0;            // exact arithmetic (see kTinySeg) needs no tolerance band
         if (!exact) {
             // everything the slide can need in ONE memory round trip: the two newest points and the four points around
@@ -662,11 +703,22 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
 #ifdef FTL_WAVE_TIMES
         if (exact) E.dbg_walk += 1;
 #endif
-#ifndef FTL_ABLATE_EXACT
-        if (exact) Gn = g_green_walk<G>(P, E, W, tiny);
-#endif
-        E.green_count = Gn; E.green_w = W; E.green_len = nn; E.green_tiny = tiny;
+        g_walk = exact;
     }
+#ifndef FTL_ABLATE_EXACT
+    if (REG && c.rand_fps_hi > 0) {     // random frame counts: some groups of the wavefront sit this frame out, the walk stays inside the group
+        if (g_walk) Gn = g_green_walk<G>(P, E, W, tiny);
+    } else {   // the full walks of this frame, one env at a time by the whole wavefront (after a reset; once per 1024 points; near a threshold)
+        unsigned long long need = __ballot(g_walk && E.valid && r == 0);
+        while (need) {
+            const int L = __ffsll((long long)need) - 1; need &= need - 1;
+            const int envL = __builtin_amdgcn_readlane(E.env, L), nL = __builtin_amdgcn_readlane(E.traj_len, L);
+            const WalkRes wr = w_green_walk(reinterpret_cast<const float2*>(P.traj + (size_t)envL * c.traj_cap * 2), nL, c.max_distance);
+            if (((int)threadIdx.x & ~(G - 1)) == (L & ~(G - 1))) { Gn = wr.Gc; W = wr.wlen; tiny = wr.tiny; }
+        }
+    }
+#endif
+    if (g_upd) { E.green_count = Gn; E.green_w = W; E.green_len = E.traj_len; E.green_tiny = tiny; }
 #endif
     FTL_TIC(1);
     const int Gc = E.green_count, n = E.traj_len;
