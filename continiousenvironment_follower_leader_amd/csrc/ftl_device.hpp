@@ -8,9 +8,9 @@
 //       an env on lane r of its group, list-shaped work strided over the group.
 //   ftl_rays_kernel (below) -- LeaderCorridor_Prev_lasers_v2.scan (sensors.py:883-962) and its relatives for every ray sensor: one
 //       wavefront per env; obstacle sources culled into a small LDS table (near rects with their FACING edges, references into a float32
-//       copy of the corridor ring, green caps); one (sensor, segment) item per lane works out the arc of rays that can reach its
-//       segment and runs the reference's intersection test for those; nearest squared distance per (ray, snapshot) by a 64-bit LDS
-//       atomic min; rows written sensor by sensor.
+//       copy of the corridor ring, green caps); one segment per lane works out the arc of rays that can reach it, every sensor turns
+//       the arc into (segment, ray) candidates, and the candidates of a chunk go through the reference's intersection test 64 at a
+//       time; nearest squared distance per (ray, snapshot) by a 64-bit LDS atomic min; rows written sensor by sensor.
 //   ftl_aux_kernel / ftl_tracker1_kernel (ftl_aux.hpp), ftl_gz_kernel (ftl_gazebo.hpp) -- the sensors and the tracker variants outside
 //       the headline configs; launched only when a config has them.
 // No MFMA: there is no dense contraction anywhere on this path.
@@ -345,11 +345,11 @@ __device__ __forceinline__ bool hit_segment(float cx, float cy, double ex, doubl
 //   table in LDS (segment f32x4 + bit mask of the snapshots that contain it).  A segment wholly outside the reach box
 //   cannot intersect any ray, so dropping it is exact.
 // Phase 2 (one RAY per lane): ray ends of all sensors (sensors.py:888-891) and the per-(ray, snapshot) minima.
-// Phase 3 (one (SENSOR, SEGMENT) pair per lane): the lane works out which rays of that sensor can possibly reach its
-//   segment -- those whose direction falls inside the arc the segment subtends at the follower, widened by a slack that
-//   dwarfs every rounding error -- and runs the reference's intersection test only for them (typically 1-4 of the 12/24
-//   rays).  A hit is folded into the nearest squared distance of (ray, snapshot) with a 64-bit LDS atomic min
-//   (non-negative doubles order like their bit patterns).
+// Phase 3 (one SEGMENT of the table per lane): the lane works out once what its segment subtends at the follower; every sensor of
+//   the pass then maps that arc -- widened by a slack that dwarfs every rounding error -- to its own ray indices (typically 0-3 of
+//   the 12 / 24 rays) and appends (segment lane, ray) pairs to a candidate list in LDS.  The list is tested densely, 64 pairs per
+//   pass, with the reference's intersection test; a hit is folded into the nearest squared distance of (ray, snapshot) with a
+//   64-bit LDS atomic min (non-negative doubles order like their bit patterns).
 // Phase 4 (one RAY per lane): H minima -> the H output rows of the ray.
 // HM = compile-time number of history accumulators: 5, 8, 10 (the shipped training configs) or FTL_HMAX = 12
 // atan2 for the candidate-ray arc of phase 3 only: |error| <= 2e-5 rad (Abramowitz-Stegun 4.4.47 polynomial on [0,1] +
