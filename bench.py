@@ -7,7 +7,7 @@ finished episodes from the scenario pool inside the same launch.
 
 Workloads (BASELINE.json configs):
   B (default, the configuration the metric is quoted on): 35 rocks + 2 walls + 1 dynamic obstacle, tracker_v2 +
-     LeaderCorridor_Prev_lasers_v2 x2 (12 rays all edges, 24 rays obstacles, H=5), 65,536 envs per GPU;
+     LeaderCorridor_Prev_lasers_v2 x2 (12 rays all edges, 24 rays obstacles, H=5), 65,536 envs IN TOTAL (all of them on the one GPU at N = 1);
   D: 100 rocks, one 180-ray Prev_lasers_v2 (the LaserPrevSensor replacement), 4,096 envs;
   E: the "hardcore" parameter set (2 bears, leader speed / acceleration regimes, 5 frames per step), 32,768 envs per GPU;
   F: the reference's shipped training config (random 30-70 frames per step, H=10) -- information only.
@@ -15,8 +15,10 @@ Workloads (BASELINE.json configs):
 The env population is AGED in a fixed untimed phase before the counted warm-up (--age steps, default 300), so that the
 timed region sees the steady-state mix of episode ages whatever --warmup says.
 
-Multi-GPU: independent env shards per rank (weak scaling; shard.py), no data-path collective; ONE all_reduce of the
-8-entry episode-metrics vector (accumulated on the device by the frame kernel) after the timed region.
+Multi-GPU: independent contiguous env shards per rank (shard.py), no data-path collective; ONE all_reduce of the 8-entry
+episode-metrics vector (accumulated on the device by the frame kernel) after the timed region.  Workload B keeps BASELINE's
+65,536 envs IN TOTAL at every N ("scaling": "strong"; 8,192 per GPU at N = 8 = config C of SURVEY.md 8(d)); workload E is defined
+per GPU (32,768 each, "weak").  --scaling / --total-envs / --envs-per-gpu override.
 
 Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W] [--workload B|D|E|F]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -37,8 +39,6 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-
-DEFAULT_ENVS = {"B": 65536, "D": 4096, "E": 32768, "F": 65536, "C": 65536, "L": 65536, "T": 65536}
 
 
 def bytes_per_env_step(cfg, G, Cn):
@@ -62,46 +62,63 @@ def make_actions(cfg, n, n_sets, seed, device):
     return torch.stack([v, w], dim=-1).contiguous().to(device)
 
 
-def cpu_baseline(cfg, pool, n_envs, steps, seed, label):
+def cpu_baseline(cfg, pool, n_envs, steps, age, seed, label):
     """The CPU oracle (oracle/ftl_oracle.c, a port of the reference's algorithm; the reference itself is Python
     and cannot travel to the GPU box) timed on this host's cores with OpenMP over envs -- a REPORTED baseline on a
-    bounded sample of the same workload, not the thing measured above."""
+    bounded sample of the same workload, not the thing measured above.  Like the GPU leg it runs on an AGED population with
+    finished episodes restarted from the next pool entry (the oracle has no in-kernel auto-reset: the host loop resets the done
+    envs between steps, inside the timed region)."""
     import ctypes as C
     from oracle import OracleEnv, load_oracle
     t = {k: v.cpu().numpy() for k, v in pool.t.items()}
     P = pool.n
-    # the one-GPU box grants a 16-core share even though more cores are visible: never oversubscribe it
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("FTL_CPU_THREADS", "16")))
+    # the one-GPU box grants a 16-core CPU share even though more cores are visible: use all of the share, never oversubscribe it
+    visible = len(os.sched_getaffinity(0))
+    cores = min(visible, int(os.environ.get("FTL_CPU_THREADS", "16")))
     lib = load_oracle()
-    envs = []
+    envs, scen = [], np.arange(n_envs) % P
+
+    def reset(e):
+        i = scen[e]
+        envs[e].reset(static_rects=t["static_rects"][i], robot_pos=t["robot_pos"][i], robot_dir=t["robot_dir"][i],
+                      robot_rect=t["robot_rect"][i], route=t["route"][i, :t["route_len"][i]],
+                      init_traj=t["init_traj"][i, :t["init_traj_len"][i]])
     for e in range(n_envs):
-        i = e % P
-        o = OracleEnv(cfg)
-        o.reset(static_rects=t["static_rects"][i], robot_pos=t["robot_pos"][i], robot_dir=t["robot_dir"][i],
-                robot_rect=t["robot_rect"][i], route=t["route"][i, :t["route_len"][i]],
-                init_traj=t["init_traj"][i, :t["init_traj_len"][i]])
-        envs.append(o)
+        envs.append(OracleEnv(cfg, env_id=e))
+        reset(e)
     arr = (C.c_void_p * n_envs)(*[o.h for o in envs])
     L = max(cfg.lasers_len, 1)
     obs = np.zeros((n_envs, 10), np.float32); las = np.zeros((n_envs, L), np.float32); tg = np.zeros((n_envs, 2))
     rew = np.zeros(n_envs); done = np.zeros(n_envs, np.uint8); st = np.zeros((n_envs, 3), np.uint8)
-    acts = make_actions(cfg, n_envs, steps, seed, "cpu").numpy()
+    acts = make_actions(cfg, n_envs, 16, seed, "cpu").numpy()
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    n_resets = 0
+
+    def run(k0, k1):
+        nonlocal n_resets
+        for k in range(k0, k1):
+            a = np.ascontiguousarray(acts[k % 16])
+            lib.ftlo_step_batch(arr, n_envs, p(a), p(obs), p(las), p(tg), p(rew), p(done), p(st), cores)
+            for e in np.nonzero(done)[0]:
+                scen[e] = (scen[e] + n_envs) % P
+                reset(e)
+                n_resets += 1
+    run(0, age)
+    n_resets = 0
     t0 = time.perf_counter()
-    for k in range(steps):
-        a = np.ascontiguousarray(acts[k])
-        lib.ftlo_step_batch(arr, n_envs, p(a), p(obs), p(las), p(tg), p(rew), p(done), p(st), cores)
+    run(age, age + steps)
     dt = time.perf_counter() - t0
     return dict(value=n_envs * steps / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample="%d config-%s envs x %d steps of oracle/ftl_oracle.c (C restatement of the reference, OpenMP over envs, "
-                       "no auto-reset), %.1f s wall" % (n_envs, label, steps, dt))
+                sample="%d config-%s envs x %d steps of oracle/ftl_oracle.c (C restatement of the reference, OpenMP over envs on %d threads = "
+                       "the box's CPU share, %d cores visible) after %d ageing steps, %d finished episodes restarted from the pool by the host "
+                       "loop inside the timed region, %.1f s wall" % (n_envs, label, steps, cores, visible, age, n_resets, dt))
 
 
-def build_workload(name, n, rank, seed, device):
-    """(cfg, pool, workload text, bytes per env-step, kernel names) of a workload."""
+def build_workload(name, base, seed, device):
+    """(cfg, pool, workload text, bytes per env-step, kernel names) of a workload; base = global index of this rank's first env
+    (env_id_base: the keys of the per-env random streams of row a12 stay distinct across ranks)."""
     from golden_util import GOLDEN, config_for, load_episode
     from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool
-    base = rank * n           # env_id_base: global env ids (keys of the per-env random streams of row a12) stay distinct across ranks
     if name == "B":
         pool_path = os.path.join(GOLDEN, "pool_B.npz")
         z = np.load(pool_path)
@@ -148,10 +165,15 @@ def main():
     ap.add_argument("--age", type=int, default=300,
                     help="untimed steps before the counted warm-up that bring the env population to its steady-state mix of "
                          "episode ages (independent of --warmup)")
-    ap.add_argument("--envs-per-gpu", type=int, default=0, help="0: the workload's BASELINE size (B 65,536; D 4,096; E 32,768)")
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="fixed batch per GPU (implies weak scaling); 0: the workload's BASELINE size")
+    ap.add_argument("--total-envs", type=int, default=0, help="fixed total batch split over the GPUs (implies strong scaling); 0: the workload's "
+                                                              "BASELINE size (B: 65,536 in total)")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="default: strong for workload B (BASELINE: 65,536 envs in total on 1/2/4/8 GPUs), weak for the per-GPU workloads (E: 32,768 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--cpu-age", type=int, default=150, help="untimed ageing steps of the CPU baseline's population")
     ap.add_argument("--kernel-steps", type=int, default=100, help="steps of the per-kernel HIP-event pass after the timed region")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--workload", default="B", choices=["B", "D", "E", "F", "C", "L", "T"],
@@ -185,12 +207,13 @@ def main():
 
     from continiousenvironment_follower_leader_amd import shard
     from continiousenvironment_follower_leader_amd.vec_game import VecGame
-    n = a.envs_per_gpu or DEFAULT_ENVS[a.workload]
-    cfg, pool, workload_text, bpe, knames = build_workload(a.workload, n, rank, a.seed, device)
+    sh, scaling = shard.plan(a.workload, rank, world, a.scaling, a.total_envs, a.envs_per_gpu)
+    n = sh.n
+    cfg, pool, workload_text, bpe, knames = build_workload(a.workload, sh.lo, a.seed, device)
     env = VecGame(n, device=device, config=cfg)
     env.load_scenarios(pool)
-    # env e of rank r is GLOBAL env r*n + e and starts from scenario (seed*1000003 + r*n + e) mod P; auto-reset walks on by n_envs
-    env.reset(shard.scenario_index(a.seed, rank * n, n, pool.n))
+    # env e of this rank is GLOBAL env sh.lo + e and starts from scenario (seed*1000003 + sh.lo + e) mod P; auto-reset walks on by n_envs
+    env.reset(shard.scenario_index(a.seed, sh.lo, n, pool.n))
     n_sets = 16
     acts = make_actions(cfg, n, n_sets, a.seed * 7919 + rank, device)
     torch.cuda.synchronize()
@@ -226,39 +249,57 @@ def main():
     # its all-reduce is the only collective of the path, off the timed region
     metrics = env.episode_metrics().clone()
     n_err, err_bits = env.error_report()
-    tmax = torch.tensor([dt, float(n_err)], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt, float(n_err), float(n)], dtype=torch.float64, device=device)
+    ebits = torch.tensor([(err_bits >> b) & 1 for b in range(16)], dtype=torch.float64, device=device)
     if dist is not None:
         if a.backend == "gloo":                      # gloo reduces host tensors
-            tmax, metrics = tmax.cpu(), metrics.cpu()
+            tmax, metrics, ebits = tmax.cpu(), metrics.cpu(), ebits.cpu()
         tm = tmax[:1].clone()
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         tmax[0] = tm[0]
         shard.reduce_metrics(metrics)
-        errs = tmax[1:].clone()
-        dist.all_reduce(errs, op=dist.ReduceOp.SUM)
-        n_err = int(errs.item())
+        sums = tmax[1:].clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        tmax[1:] = sums
+        dist.all_reduce(ebits, op=dist.ReduceOp.MAX)   # bitwise OR of the ranks' error words, one bit per element
     dt = float(tmax[0].item())
-    total_envs = n * world
+    n_err = int(tmax[1].item())
+    err_bits = sum(1 << b for b in range(16) if ebits[b].item() > 0)
+    total_envs = int(tmax[2].item())                   # the units all ranks processed per step
     value = total_envs * a.steps / dt
 
     # per-kernel durations: a separate pass on the same (still steady-state) population with HIP events around each launch
-    ktimes = None
+    ktimes, kmode = None, "HIP events around every launch of %d further steps on the same population" % a.kernel_steps
     if rank == 0 and a.kernel_steps > 0:
+        tenv = env
         try:
             env.kernel_timing(True)
-            for k in range(a.kernel_steps):
-                env.step(acts[(k0 + k) % n_sets], auto_reset=True)
-            ktimes = env.kernel_times()
-            env.kernel_timing(False)
         except NotImplementedError:
-            ktimes = None                               # two-stream mode (workload F)
+            # two-stream mode (random_frames_per_step: the halves of the batch overlap on two streams, so no kernel has a duration of
+            # its own).  The per-kernel figures then come from a single-stream handle (FTL_SPLIT=0) continuing the SAME population.
+            os.environ["FTL_SPLIT"] = "0"
+            tenv = VecGame(n, device=device, config=cfg)
+            del os.environ["FTL_SPLIT"]
+            tenv.load_scenarios(pool)
+            torch.cuda.synchronize()
+            tenv.state.view(-1)[tenv._state_off:tenv._state_off + env.state.numel() - 256].copy_(
+                env.state.view(-1)[env._state_off:env._state_off + env.state.numel() - 256])
+            tenv.kernel_timing(True)
+            kmode = "a single-stream pass (FTL_SPLIT=0) of %d steps continuing the same population; the timed region itself runs the two halves " \
+                    "of the batch on two streams" % a.kernel_steps
+        for k in range(a.kernel_steps):
+            tenv.step(acts[(k0 + k) % n_sets], auto_reset=True)
+        ktimes = tenv.kernel_times()
+        tenv.kernel_timing(False)
+        if tenv is not env:
+            tenv.close()
 
     if rank == 0:
         m = metrics.tolist()
         if ktimes:
-            # the dominant kernel's roofline: algorithmic bytes of one launch / its average duration
-            dom = "rays" if ktimes["rays_us"] >= ktimes["frames_us"] else "frames"
-        kernel_ms = (ktimes["frames_us"] + ktimes["rays_us"] + ktimes["regroup_us"]) * 1e-3 if ktimes else step_ms
+            # the dominant kernel of the step
+            dom = max(("frames", "rays", "aux"), key=lambda k: ktimes[k + "_us"])
+        kernel_ms = (ktimes["frames_us"] + ktimes["rays_us"] + ktimes["aux_us"] + ktimes["regroup_us"]) * 1e-3 if ktimes else step_ms
         launch_bytes = bpe * n
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         prof = {}
@@ -273,16 +314,18 @@ def main():
                 "kernel": "%s + %s (one step = both launches on one stream + the regroup kernels every 2nd step; HBM is the "
                           "contract roofline, the ray kernel is VALU-issue bound -- see valu)" % knames,
                 "kernel_ms": kernel_ms, "step_ms_events": step_ms, "bytes_per_env_step": bpe,
-                "kernels_us": ktimes, "valu": prof.get("valu")}
+                "kernels_us": ktimes, "kernels_us_from": kmode if ktimes else None, "valu": prof.get("valu")}
         if ktimes:
-            roof["dominant_kernel"] = knames[1] if dom == "rays" else knames[0]
+            roof["dominant_kernel"] = {"rays": knames[1], "frames": knames[0], "aux": "ftl_aux_kernel"}[dom]
         line = {
             "metric": "env-steps/sec at 65,536 parallel envs; 1/2/4/8 MI355X scaling",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_text % (n, pool.n), "workload_id": a.workload,
-                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": "independent env shards x%d%s" % (world, " (gloo rehearsal)" if (world > 1 and a.backend == "gloo") else ""),
+                       "envs_per_gpu": n, "total_envs": total_envs,
+                       "parallelism": "independent contiguous env shards x%d, %s%s" % (world, "the same total at every N" if scaling == "strong" else "a fixed batch per GPU",
+                                                                                 " (gloo rehearsal)" if (world > 1 and a.backend == "gloo") else ""),
                        "age_steps": a.age,
                        "episode_metrics": dict(zip(shard.METRIC_NAMES, m)),
                        "mean_return": m[1] / m[0] if m[0] else None, "mean_episode_frames": m[2] / m[0] if m[0] else None,
@@ -290,7 +333,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, pool, min(a.cpu_envs, n), a.cpu_steps, a.seed, a.workload)
+            line["cpu_baseline"] = cpu_baseline(cfg, pool, min(a.cpu_envs, n), a.cpu_steps, a.cpu_age, a.seed, a.workload)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

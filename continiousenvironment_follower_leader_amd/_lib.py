@@ -67,8 +67,9 @@ def load():
     lib.ftl_load_scenarios.argtypes = [vp, C.POINTER(abi.Scenarios)]
     lib.ftl_reset.argtypes = [vp, vp, vp, C.POINTER(abi.Outputs), vp]
     lib.ftl_step.argtypes = [vp, vp, C.POINTER(abi.Outputs), u32, vp]
+    lib.ftl_step_encoded.argtypes = [vp, vp, i32, C.POINTER(abi.Outputs), u32, vp]
     lib.ftl_kernel_timing.argtypes = [vp, i32]
-    lib.ftl_kernel_times.argtypes = [vp, C.POINTER(C.c_double * 3), C.POINTER(i32)]
+    lib.ftl_kernel_times.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(i32)]
     lib.ftl_episode_metrics.argtypes = [vp, vp, vp, u32, vp]
     lib.ftl_episode_metrics.restype = C.c_int
     lib.ftl_generate_scenarios.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.ScenParams), vp, i32, i32,
@@ -94,7 +95,7 @@ def load():
 
 
 EXPORTS = ("ftl_create", "ftl_destroy", "ftl_lasers_len", "ftl_get_config", "ftl_state_bytes", "ftl_bind_state",
-           "ftl_state_field", "ftl_load_scenarios", "ftl_reset", "ftl_step", "ftl_last_error", "ftl_generate_scenarios",
+           "ftl_state_field", "ftl_load_scenarios", "ftl_reset", "ftl_step", "ftl_step_encoded", "ftl_last_error", "ftl_generate_scenarios",
            "ftl_episode_metrics", "ftl_kernel_timing", "ftl_kernel_times",
            "ftl_gz_create", "ftl_gz_destroy", "ftl_gz_state_bytes", "ftl_gz_bind_state", "ftl_gz_lasers_len", "ftl_gz_reset", "ftl_gz_step",
            "ftl_gz_state_field")

@@ -4,7 +4,7 @@ Field order and types must match the header exactly; ``tests/test_abi.py`` check
 against ``ftl_sizeof_*`` exported by the library."""
 import ctypes as C
 
-FTL_ABI_VERSION = 2
+FTL_ABI_VERSION = 3
 FTL_MAX_BEARS = 6
 FTL_MAX_LASERS = 4
 FTL_MAX_AUX = 8
@@ -21,6 +21,8 @@ LEADER = ("moving", "crash", "finished")
 
 FTL_ERR_TRAJ_OVERFLOW, FTL_ERR_CORR_OVERFLOW, FTL_ERR_EMPTY_CORRIDOR, FTL_ERR_TRACKER_SEED, FTL_ERR_HIST1_OVERFLOW = 1, 2, 4, 8, 16
 FTL_ERR_LIDAR_OVERFLOW = 32
+FTL_ERR_BAD_ACTION = 64
+FTL_ACTION_BOX2, FTL_ACTION_DISCRETE, FTL_ACTION_TURN = 0, 1, 2
 FTL_STEP_AUTO_RESET = 1
 FTL_N_METRICS = 8
 FTL_METRICS_CLEAR = 1
@@ -136,7 +138,8 @@ class ScenParams(C.Structure):
                 ("trajectory_saving_period", C.c_int32), ("planner", C.c_int32),
                 ("min_distance", C.c_double), ("max_distance", C.c_double),
                 ("leader_pos_epsilon", C.c_double), ("leader_margin", C.c_double),
-                ("leader_w", C.c_double), ("leader_h", C.c_double), ("leader_max_speed", C.c_double)]
+                ("leader_w", C.c_double), ("leader_h", C.c_double), ("leader_max_speed", C.c_double),
+                ("fixed_route", C.c_void_p), ("fixed_route_len", C.c_int32), ("_pad", C.c_int32)]
 
 
 SCEN_FOUND, SCEN_DONE_AT_RESET, SCEN_ROUTE_OVERFLOW, SCEN_TRAJ_OVERFLOW, SCEN_REF_RAISES = 1, 2, 4, 8, 16

@@ -35,7 +35,7 @@ struct ftl_handle {
     Field fields[FTL_N_FIELDS];
     void* mt_mem;            // partial sums of ftl_episode_metrics (library-owned)
     bool timing;             // ftl_kernel_timing: events around every launch of a step
-    std::vector<hipEvent_t> tev;   // 4 per timed step: before frames | after frames | after rays | after regroup
+    std::vector<hipEvent_t> tev;   // 5 per timed step: before frames | after frames | after rays | after aux | after regroup
     size_t tev_used;
     bool bound, have_scen;
     bool regroup;            // envs are regrouped by expected cost after every launch (off: FTL_NO_REGROUP=1, or too many envs)
@@ -45,6 +45,7 @@ struct ftl_handle {
     // optionally the slot groups are stepped as two interleaved halves on two streams (the caller's stream waits for the side
     // stream): the ray kernel of one half fills the tail of the other half's frame kernel
     hipStream_t side; hipEvent_t ev_fork, ev_join; bool split;
+    size_t lds_pad;          // FTL_DEBUG_LDS_PAD (diagnostic: lowers the frame kernel's occupancy without touching the code), read once at create
 };
 
 namespace {
@@ -78,7 +79,11 @@ int validate(const ftl_config& c, std::string& why) {
     for (int j = 0; j < c.n_aux; j++) {
         const ftl_aux_cfg& a = c.aux[j];
         REQ(a.kind >= FTL_AUX_LIDAR && a.kind <= FTL_AUX_TRACK_RADAR, "aux %d: unknown sensor kind", j);
-        if (a.kind == FTL_AUX_LIDAR) REQ(a.n_angles > 0 && a.n_angles <= 512 && a.points_number > 0 && a.range_px > 0 && !a.return_all_points, "aux %d: bad lidar parameters", j);
+        if (a.kind == FTL_AUX_LIDAR) {
+            REQ(a.n_angles > 0 && a.n_angles <= 512 && a.points_number > 0 && a.range_px > 0 && !a.return_all_points, "aux %d: bad lidar parameters", j);
+            // the (ray, marching point) index of the lidar is split with a float quotient that is exact below 2^16 items (ftl_aux.hpp)
+            REQ(a.points_number <= 1024 && a.n_angles * a.points_number < 65536, "aux %d: lidar with more than 1024 points per ray or 65535 (ray, point) pairs", j);
+        }
         else {
             REQ(c.has_tracker != 0, "aux %d: a leader-track detector needs a tracker (classes.py:272 would raise NameError)", j);
             REQ(a.seq_len > 0 && a.detectable >= 0 && a.detectable <= (a.kind == FTL_AUX_TRACK_RADAR ? 2 : 1), "aux %d: bad detector parameters", j);
@@ -232,9 +237,12 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
                            + rects * 8 + 32                   /* facing-edge list (u16 x 4 per rect) + edge counters */
                            + (size_t)FTL_PAIR_CAP * 2 + 16);  /* candidate list of phase 3 */
     }
-    if (const char* pad = getenv("FTL_DEBUG_LDS_PAD_RAYS")) P.lds_rays += atoi(pad);      // diagnostic: occupancy of the ray kernel without touching the code
+    auto debug_pad = [](const char* name) { const char* v = getenv(name); const int p = v ? atoi(v) : 0; return p < 0 ? 0 : (p > 48 * 1024 ? 48 * 1024 : p); };
+    P.lds_rays += debug_pad("FTL_DEBUG_LDS_PAD_RAYS");      // diagnostic: occupancy of the ray kernel without touching the code
+    h->lds_pad = (size_t)debug_pad("FTL_DEBUG_LDS_PAD");
     if (getenv("FTL_DEBUG_PRINT_LDS")) fprintf(stderr, "ftl: ray kernel LDS %d B per env\n", P.lds_rays);
     if (P.lds_rays > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "config needs more than 64 KiB of LDS per env"); }
+    if (ftl_aux_lds_bytes(*cfg) > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "the compas / lidar / radar sensors of this config need more than 64 KiB of LDS per env"); }
     *out = h;
     return FTL_OK;
 }
@@ -345,9 +353,9 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
     // (the halves are interleaved wavefront by wavefront, so both see the same mix of the cost-sorted slots)
     // optional per-kernel timing (ftl_kernel_timing): up to 512 steps of 4 events each, single-stream mode only
     hipEvent_t* tev = nullptr;
-    if (h->timing && !h->split && call.mode == 0 && h->tev_used + 4 <= 4 * 512) {
-        while (h->tev.size() < h->tev_used + 4) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return fail(FTL_E_DEVICE, "hipEventCreate"); h->tev.push_back(ev); }
-        tev = h->tev.data() + h->tev_used; h->tev_used += 4;
+    if (h->timing && !h->split && call.mode == 0 && h->tev_used + 5 <= 5 * 512) {
+        while (h->tev.size() < h->tev_used + 5) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return fail(FTL_E_DEVICE, "hipEventCreate"); h->tev.push_back(ev); }
+        tev = h->tev.data() + h->tev_used; h->tev_used += 5;
     }
     auto launch_range = [&](int part, int parts, hipStream_t s) {
         const int epw0 = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
@@ -358,7 +366,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         const bool reg = h->P.cfg.n_speed_regime >= 0 || h->P.cfg.n_acc_regime >= 0 || h->P.cfg.rand_fps_hi > 0;
         const int epw = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
         size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
-        if (const char* pad = getenv("FTL_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);      // diagnostic: lower the occupancy without touching the code
+        lds += h->lds_pad;
         const dim3 grid((count + epw - 1) / epw), block(FTL_WAVE);
         if (tev) (void)hipEventRecord(tev[0], s);
         if (h->P.R <= 4) {
@@ -409,6 +417,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         for (int k = 0; k < h->P.cfg.n_lasers; k++) aux = aux || h->P.cfg.lasers[k].compas != 0;
         if (aux) hipLaunchKernelGGL(ftl_aux_kernel, dim3((unsigned)h->P.n_envs), dim3(FTL_WAVE), ftl_aux_lds_bytes(h->P.cfg), (hipStream_t)stream, h->dP, call);
     }
+    if (tev) (void)hipEventRecord(tev[3], (hipStream_t)stream);
     // the frame kernel left every env's cost class for its next step: rebuild the slot -> env map.  The classes are stable
     // from step to step unless the frame count is random, so every second launch is enough then.
     if (h->regroup && (h->P.cfg.rand_fps_hi > 0 || call.mode == 1 || (h->rg_launches++ % h->rg_every) == 0)) {
@@ -418,7 +427,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         hipLaunchKernelGGL(ftl::ftl_regroup_count_kernel, dim3(nb), dim3(FTL_RG_BLOCK), 0, (hipStream_t)stream, h->dP, tot);
         hipLaunchKernelGGL(ftl::ftl_regroup_scatter_kernel, dim3(nb), dim3(FTL_RG_BLOCK), 0, (hipStream_t)stream, h->dP, (const int*)tot, tot_next);
     }
-    if (tev) (void)hipEventRecord(tev[3], (hipStream_t)stream);
+    if (tev) (void)hipEventRecord(tev[4], (hipStream_t)stream);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
     return FTL_OK;
@@ -437,18 +446,23 @@ int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const
     int rc = check_out(h, out);
     if (rc) return rc;
     if (out->policy_obs && h->P.pol_h <= 0) return fail(FTL_E_INVALID, "policy_obs needs the same max_prev_obs on every ray sensor");
-    FtlCall call; call.mode = 1; call.scen_idx = scen_idx; call.mask = mask; call.out = *out; call.action = nullptr; call.flags = 0;
+    FtlCall call; call.mode = 1; call.scen_idx = scen_idx; call.mask = mask; call.out = *out; call.action = nullptr; call.flags = 0; call.action_kind = FTL_ACTION_BOX2;
     return launch(h, call, stream);
 }
 
 int ftl_step(ftl_handle* h, const double* action, const ftl_outputs* out, uint32_t flags, void* stream) {
+    return ftl_step_encoded(h, action, FTL_ACTION_BOX2, out, flags, stream);
+}
+
+int ftl_step_encoded(ftl_handle* h, const void* action, int32_t encoding, const ftl_outputs* out, uint32_t flags, void* stream) {
     if (!h || !action) return fail(FTL_E_INVALID, "null argument");
+    if (encoding < FTL_ACTION_BOX2 || encoding > FTL_ACTION_TURN) return fail(FTL_E_INVALID, "unknown action encoding");
     if (!h->bound) return fail(FTL_E_STATE, "ftl_bind_state has not been called");
     if (!h->have_scen) return fail(FTL_E_STATE, "ftl_load_scenarios has not been called");
     int rc = check_out(h, out);
     if (rc) return rc;
     if (out->policy_obs && h->P.pol_h <= 0) return fail(FTL_E_INVALID, "policy_obs needs the same max_prev_obs on every ray sensor");
-    FtlCall call; call.mode = 0; call.action = action; call.out = *out; call.flags = flags; call.scen_idx = nullptr; call.mask = nullptr;
+    FtlCall call; call.mode = 0; call.action = (const double*)action; call.action_kind = encoding; call.out = *out; call.flags = flags; call.scen_idx = nullptr; call.mask = nullptr;
     return launch(h, call, stream);
 }
 
@@ -462,13 +476,13 @@ int ftl_kernel_timing(ftl_handle* h, int32_t enable) {
 int ftl_kernel_times(ftl_handle* h, double* ms, int32_t* n_steps) {
     if (!h || !ms || !n_steps) return fail(FTL_E_INVALID, "null argument");
     if (h->split) return fail(FTL_E_UNSUPPORTED, "per-kernel timing is not available in the two-stream mode");
-    ms[0] = ms[1] = ms[2] = 0.0; *n_steps = 0;
+    ms[0] = ms[1] = ms[2] = ms[3] = 0.0; *n_steps = 0;
     if (h->tev_used == 0) return FTL_OK;
     (void)hipSetDevice(h->device);
     hipError_t e = hipEventSynchronize(h->tev[h->tev_used - 1]);
     if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
-    for (size_t i = 0; i + 4 <= h->tev_used; i += 4) {
-        for (int k = 0; k < 3; k++) {
+    for (size_t i = 0; i + 5 <= h->tev_used; i += 5) {
+        for (int k = 0; k < 4; k++) {
             float t = 0.0f;
             e = hipEventElapsedTime(&t, h->tev[i + k], h->tev[i + k + 1]);
             if (e != hipSuccess) return fail(FTL_E_DEVICE, std::string("hipEventElapsedTime: ") + hipGetErrorString(e));

@@ -75,6 +75,7 @@ struct FtlCall {
     const double* action; const int32_t* scen_idx; const uint8_t* mask;
     ftl_outputs out;
     uint32_t flags; int32_t mode;      // mode 0 = step, 1 = reset
+    int32_t action_kind;               // FTL_ACTION_*: how `action` is encoded (ftl_step_encoded)
     int32_t part, parts, epw;          // this launch covers the slot groups (epw consecutive slots = one frame-kernel wavefront)
                                        // part, part + parts, part + 2*parts, ... of the slot -> env permutation
 };

@@ -1272,7 +1272,16 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         FTL_TIC(4);
         // One memory round trip for everything the frames need besides the state: the action and the scenario's static rects
         // (culled into the near list).
-        const double a0 = C.action[2 * (size_t)E.env], a1 = C.action[2 * (size_t)E.env + 1];
+        double a0, a1;
+        if (C.action_kind == FTL_ACTION_BOX2) { a0 = C.action[2 * (size_t)E.env]; a1 = C.action[2 * (size_t)E.env + 1]; }
+        else if (C.action_kind == FTL_ACTION_DISCRETE) {        // ENV:918-922 with the table of ENV:362-367
+            const int k = reinterpret_cast<const int32_t*>(C.action)[E.env];
+            const double mr = P.cfg.follower.max_rotation_speed;
+            a0 = P.cfg.follower.max_speed;
+            a1 = k == 0 ? -mr : k == 1 ? -mr / 2 : k == 3 ? mr / 2 : k == 4 ? mr : 0.0;
+            if (k < 0 || k > 4) E.error |= FTL_ERR_BAD_ACTION;    // reference: KeyError
+        } else { a0 = 0.25; a1 = C.action[E.env]; }            // ENV:924-925
+
         // this env's block bounding boxes stay in global memory: the searches that read them are rare now (an LDS copy per
         // step measured 2 % slower than no copy once the caches of g_frame were in place, and cost 0.6 KB of traffic)
         float4* bbl = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (P.cfg.traj_cap / FTL_TRAJ_BLOCK);

@@ -308,8 +308,9 @@ void generate_one(const ftl_config& c, const ftl_scen_params& sp, int64_t seed, 
         }
     };
     long f1x = 0, f1y = 0, f2x = 0, f2y = 0, f3x = 0, f3y = 0;
-    finish_point(20, 20, (long)(W / 2.0), H - 20, f1x, f1y);
-    if (sp.multiple_end_points && ok) {                                       // ENV:470-481
+    const bool fixed = sp.planner == 2;                                        // trajectory= of the constructor: ENV:470 skips all of this
+    if (!fixed) finish_point(20, 20, (long)(W / 2.0), H - 20, f1x, f1y);
+    if (!fixed && sp.multiple_end_points && ok) {                                       // ENV:470-481
         if (f1y >= H / 2.0) finish_point(20, 20, W - 20, (long)(H / 2.0), f2x, f2y);
         else finish_point(20, (long)(H / 2.0), W - 20, H - 20, f2x, f2y);
         if (ok) {
@@ -317,8 +318,10 @@ void generate_one(const ftl_config& c, const ftl_scen_params& sp, int64_t seed, 
             else finish_point(20, (long)(H / 2.0), W - 20, H - 20, f3x, f3y);
         }
     }
-    std::vector<long> route_x, route_y;
+    std::vector<double> route_x, route_y;
     bool found = ok;
+    if (ok && fixed)
+        for (int i = 0; i < sp.fixed_route_len; i++) { route_x.push_back(sp.fixed_route[2 * i]); route_y.push_back(sp.fixed_route[2 * i + 1]); }
     if (ok && sp.planner == 1) {
         // ---- generate_trajectory_astar (ENV:1632-1711): a 20 px grid, obstacles inflated by 2 x the leader's larger side, the bridge row
         // cleared, one leg to the near end of the bridge and one from its far end to the finish point
@@ -363,7 +366,7 @@ void generate_one(const ftl_config& c, const ftl_scen_params& sp, int64_t seed, 
         found = route_x.size() >= 2;                  // the reference leaves found_target_point False (ENV:1537 is D*-only): "usable" = it can be stepped
     }
     // ---- generate_trajectory_dstar (ENV:1493-1612)
-    if (ok && sp.planner != 1) {
+    if (ok && sp.planner == 0) {
         Grid g; g.rows = W / sg; g.cols = H / sg; g.obst.assign((size_t)g.rows * g.cols, 0);
         const int margin = (int)floor(sp.leader_margin * fmax(sp.leader_w, sp.leader_h) / sg);
         // order of the reference: rocks, then the two walls (irrelevant for a set of cells)
@@ -396,7 +399,7 @@ void generate_one(const ftl_config& c, const ftl_scen_params& sp, int64_t seed, 
     float fpx = lpx, fpy = lpy; double fdir = 0;
     if (ok) {
         double tx = (double)lpx, ty = (double)lpy;              // len(trajectory) == 0: cur_target_point = leader.start_position
-        if (rl >= 2) { tx = (double)route_x[1]; ty = (double)route_y[1]; }
+        if (rl >= 2) { tx = route_x[1]; ty = route_y[1]; }
         ldir = angle_to_point((double)lpx, (double)lpy, tx, ty);
         const long d = rnd.randrange((long)(sp.min_distance * 1.1), (long)(sp.max_distance * 0.9), 1, ok);
         const double th = angle_correction(ldir + 180);
@@ -425,7 +428,7 @@ void generate_one(const ftl_config& c, const ftl_scen_params& sp, int64_t seed, 
     double* ro = const_cast<double*>(out.route) + (size_t)idx * c.route_cap * 2;
     if (rl > c.route_cap) st |= FTL_SCEN_ROUTE_OVERFLOW;
     const int rn = rl < c.route_cap ? rl : c.route_cap;
-    for (int i = 0; i < rn; i++) { ro[2 * i] = (double)route_x[(size_t)i]; ro[2 * i + 1] = (double)route_y[(size_t)i]; }
+    for (int i = 0; i < rn; i++) { ro[2 * i] = route_x[(size_t)i]; ro[2 * i + 1] = route_y[(size_t)i]; }
     for (int i = rn; i < c.route_cap; i++) { ro[2 * i] = 0; ro[2 * i + 1] = 0; }
     const_cast<int32_t*>(out.route_len)[idx] = rn;
     // ---- initial leader_factual_trajectory (ENV:533-539): float32 linspace follower -> leader
@@ -460,6 +463,7 @@ extern "C" int ftl_generate_scenarios(const ftl_config* cfg, const ftl_scen_para
     if (sp->step_grid <= 0 || sp->width <= 0 || sp->height <= 0 || sp->trajectory_saving_period <= 0 || !(sp->leader_max_speed > 0)) return FTL_E_INVALID;
     if (cfg->n_static != (sp->add_obstacles ? sp->obstacle_number + 2 : 0)) return FTL_E_INVALID;
     if (cfg->n_bears != (sp->add_bear ? sp->bear_number : 0)) return FTL_E_INVALID;
+    if (sp->planner < 0 || sp->planner > 2 || (sp->planner == 2 && (sp->fixed_route_len < 0 || (sp->fixed_route_len > 0 && !sp->fixed_route)))) return FTL_E_INVALID;
     int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
     if (T < 1) T = 1;
     if (T > n) T = n > 0 ? n : 1;

@@ -109,23 +109,30 @@ class Game:
             self._vec.load_scenarios(self._generated_pool())
         self._resets_since_seed += 1
         idx = torch.tensor([self._seed % self._vec.pool.n], dtype=torch.int32)
-        self._vec.reset(idx, check_errors=True)       # a reference reset() that raises (SEN:893, 288-297) raises here too
+        # a reference reset() that raises (SEN:893, 288-297) raises here too; the check reads the error word of the episode in
+        # progress, which reset() clears like the sensors the reference rebuilds -- an episode that raised does not poison the next one
+        self._vec.reset(idx, check_errors=True, live_errors=True)
         self.simulation_number += 1
         self.done = bool(self._vec.done[0].item())
         return self._obs()
 
     def step(self, action):                                        # ENV:908-945
         cfg = self.cfg
-        if cfg.discrete_action_space:                              # ENV:918-922
-            if type(action) is np.ndarray:
-                assert action.shape[0] == 1 and action.shape[1] == 1
+        if cfg.discrete_action_space:                              # ENV:918-922, decoded on the device (ftl_step_encoded); combined with
+            if type(action) is np.ndarray:                         # constant_follower_speed ENV:925 prepends 0.25 to the decoded pair and the
+                assert action.shape[0] == 1 and action.shape[1] == 1   # follower's max_speed becomes the rotation: VecGame.step does that too
                 action = action[0, 0]
-            action = (cfg.c.follower.max_speed, cfg.discrete_rotation_speed_to_value[action])
-        if cfg.constant_follower_speed:                            # ENV:924-925: np.concatenate([[0.25], action]) -- the
-            action = (0.25, float(np.asarray(action).reshape(-1)[-1]))  # command of ENV:910-911 is overwritten by ENV:927
-        self._act[0, 0] = float(action[0])
-        self._act[0, 1] = float(action[1])
-        self._vec.step(self._act, check_errors=True)  # the reference's exceptions instead of silent error bits
+            if action not in cfg.discrete_rotation_speed_to_value:
+                raise KeyError(action)
+            act = torch.tensor([int(action)], dtype=torch.int32, device=self._device)
+        elif cfg.constant_follower_speed:                          # ENV:924-925: np.concatenate([[0.25], action]) -- the speed command of
+            a = np.concatenate([[0.25], action])                   # ENV:910-911 is overwritten by ENV:927
+            act = torch.tensor([float(a[1])], dtype=torch.float64, device=self._device)
+        else:
+            self._act[0, 0] = float(action[0])
+            self._act[0, 1] = float(action[1])
+            act = self._act
+        self._vec.step(act, check_errors=True, live_errors=True)   # the reference's exceptions instead of silent error bits
         st = self._vec.status[0].cpu().numpy()
         info = {"mission_status": abi.MISSION[st[0]], "agent_status": abi.AGENT[st[1]], "leader_status": abi.LEADER[st[2]]}
         self.done = bool(self._vec.done[0].item())

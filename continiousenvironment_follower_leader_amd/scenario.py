@@ -19,8 +19,13 @@ def scen_params(cfg: GameConfig) -> abi.ScenParams:
     kw, c = cfg.kwargs, cfg.c
     if kw["path_finding_algorythm"] not in ("dstar", "astar"):
         raise ValueError("path_finding_algorythm {} not in list:{}".format(kw["path_finding_algorythm"], ["astar", "dstar"]))
-    if kw["trajectory"] is not None:
-        raise NotImplementedError("a fixed `trajectory` needs no generated route; pass the scenario arrays yourself")
+    fixed = None
+    if kw["trajectory"] is not None:             # ENV:229, 469-470: the caller's way-points on every reset, no finish point, no planner
+        fixed = np.ascontiguousarray(np.asarray(kw["trajectory"], np.float64).reshape(-1, 2))
+    elif not kw["add_obstacles"] and kw["path_finding_algorythm"] == "dstar":
+        # generate_trajectory_dstar reads the two bridge walls (ENV:1501) that _create_obstacles, skipped at ENV:464-465, never made:
+        # the reference's reset() raises exactly this (so do its ids Test-Game-Neat-v0 and Test-Cont-Env-Auto-Follow-no-obstacles-v0)
+        raise AttributeError("'Game' object has no attribute 'obstacles1'")
     ptm = cfg.pixels_to_meter
     sp = abi.ScenParams()
     sp.width, sp.height = int(kw["game_width"]), int(kw["game_height"])
@@ -34,6 +39,9 @@ def scen_params(cfg: GameConfig) -> abi.ScenParams:
     sp.bridge_gap, sp.bridge_width = int(kw["bridge_size"][0]), int(kw["bridge_size"][1])
     sp.trajectory_saving_period = c.trajectory_saving_period
     sp.planner = 1 if kw["path_finding_algorythm"] == "astar" else 0
+    if fixed is not None:
+        sp.planner, sp.fixed_route, sp.fixed_route_len = 2, fixed.ctypes.data, len(fixed)
+        sp._keep_alive = fixed
     sp.min_distance, sp.max_distance = c.min_distance, c.max_distance
     sp.leader_pos_epsilon, sp.leader_margin = float(kw["leader_pos_epsilon"]), float(kw["leader_margin"])
     sp.leader_w, sp.leader_h = kw["leader_size"][0] * ptm, kw["leader_size"][1] * ptm    # ENV:352-353

@@ -36,6 +36,29 @@ def shard_range(n_total, rank, world):
     return Shard(rank, world, lo, lo + base + (1 if rank < extra else 0))
 
 
+# bench.py's batch sizes (BASELINE.json configs).  Workload B is quoted on 65,536 envs IN TOTAL: on N GPUs the same
+# 65,536 envs are split into N contiguous shards (config C of the survey: 8,192 per GPU at N = 8) -- strong scaling.  Config E is
+# defined per GPU (32,768 each, 262,144 at N = 8) -- weak scaling; the information-only workloads keep a fixed size per GPU too.
+TOTAL_ENVS = {"B": 65536}
+ENVS_PER_GPU = {"D": 4096, "E": 32768, "F": 65536, "C": 65536, "L": 65536, "T": 65536}
+
+
+def plan(workload, rank, world, scaling=None, total_envs=0, envs_per_gpu=0):
+    """(Shard of this rank, "strong" | "weak") for a bench workload.  ``total_envs`` / ``envs_per_gpu`` override the BASELINE size;
+    ``scaling`` overrides the workload's own mode (strong = a fixed total split over the ranks, weak = a fixed size per rank)."""
+    if total_envs and envs_per_gpu:
+        raise ValueError("give total_envs or envs_per_gpu, not both")
+    if scaling is None:
+        scaling = "weak" if envs_per_gpu else ("strong" if (total_envs or workload in TOTAL_ENVS) else "weak")
+    if scaling == "strong":
+        total = total_envs or TOTAL_ENVS.get(workload) or envs_per_gpu or ENVS_PER_GPU[workload]
+        return shard_range(int(total), rank, world), "strong"
+    if scaling != "weak":
+        raise ValueError("scaling must be 'strong' or 'weak'")
+    per = envs_per_gpu or total_envs or ENVS_PER_GPU.get(workload) or TOTAL_ENVS[workload]
+    return Shard(rank, world, rank * int(per), (rank + 1) * int(per)), "weak"
+
+
 def scenario_index(seed, env_lo, n, pool_size):
     """Scenario of global env e: pool[(seed*1000003 + e) mod P]; int32 tensor for this shard."""
     e = torch.arange(env_lo, env_lo + n, dtype=torch.int64)

@@ -87,6 +87,8 @@ class ScenarioPool:
 def error_for_bits(bits, n_envs=1):
     """Exception object for a set of FTL_ERR_* bits: the type the reference raises where it has one."""
     where = "%d env(s)" % n_envs
+    if bits & abi.FTL_ERR_BAD_ACTION:           # ENV:922: discrete_rotation_speed_to_value[action] with an action outside 0..4
+        return KeyError("Discrete(5) action outside 0..4 in %s" % where)
     if bits & abi.FTL_ERR_TRACKER_SEED:         # SEN:264-297 (the tracker is scanned before every ray sensor, CLS:263-267)
         return IndexError("pop from an empty deque (tracker seeded with fewer than 2 points or trimmed before the corridor "
                           "exists, sensors.py:288-297; %s)" % where)
@@ -172,7 +174,7 @@ class VecGame:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def reset(self, scen_idx=None, mask=None, check_errors=False):
+    def reset(self, scen_idx=None, mask=None, check_errors=False, live_errors=False):
         if self.pool is None:
             raise _lib.FtlError("load_scenarios() first")
         if scen_idx is None:
@@ -189,20 +191,39 @@ class VecGame:
         self._keep = (scen_idx, mask)
         _lib.check(self.lib.ftl_reset(self.h, scen_idx.data_ptr(), mptr, C.byref(self._out), self._stream()), self.lib)
         if check_errors:
-            self.raise_on_errors()
+            self.raise_on_errors(live_errors)
         return self.obs_num, self.lasers
 
-    def step(self, action, auto_reset=False, check_errors=False):
-        """action: f64[N,2] device tensor = (speed px/frame, signed rotation deg/frame) (ENV:927-933).
+    def step(self, action, auto_reset=False, check_errors=False, live_errors=False):
+        """action: f64[N,2] device tensor = (speed px/frame, signed rotation deg/frame) (ENV:927-933).  With
+        ``discrete_action_space=True`` an integer tensor [N] (or [N,1]) of Discrete(5) indices, with ``constant_follower_speed=True`` a
+        float tensor [N] (or [N,1]) of rotations: both are decoded on the device as ENV:909-925 does (``ftl_step_encoded``).
         ``check_errors=True`` synchronises and raises what the reference would have raised in any env (``raise_on_errors``);
         the default leaves the per-env sticky error words for ``error_report()`` so that the step stays asynchronous."""
-        if action.dtype != torch.float64 or not action.is_contiguous() or action.device != self.device \
-                or tuple(action.shape) != (self.n, 2):
-            raise ValueError("action must be a contiguous float64 [n_envs, 2] tensor on %s" % self.device)
         flags = abi.FTL_STEP_AUTO_RESET if auto_reset else 0
-        _lib.check(self.lib.ftl_step(self.h, action.data_ptr(), C.byref(self._out), flags, self._stream()), self.lib)
+        enc = abi.FTL_ACTION_BOX2
+        if action.device != self.device:
+            raise ValueError("action must live on %s" % self.device)
+        if self.cfg.discrete_action_space or self.cfg.constant_follower_speed:
+            if tuple(action.shape) not in ((self.n,), (self.n, 1)):
+                raise ValueError("action must be [n_envs] or [n_envs, 1] for this action space (ENV:358-372)")
+            if self.cfg.discrete_action_space and self.cfg.constant_follower_speed:
+                # ENV:922 then ENV:925: np.concatenate([[0.25], (max_speed, rotation)]) -- the follower's max_speed ends up as the rotation
+                action = torch.tensor([0.25, self.cfg.c.follower.max_speed], dtype=torch.float64, device=self.device).repeat(self.n, 1)
+            elif self.cfg.discrete_action_space:
+                if action.dtype.is_floating_point or action.dtype == torch.bool:
+                    raise ValueError("Discrete(5) actions must be an integer tensor")
+                action, enc = action.reshape(self.n).to(torch.int32).contiguous(), abi.FTL_ACTION_DISCRETE
+            else:
+                if not action.dtype.is_floating_point:
+                    raise ValueError("Box(1) actions must be a float tensor")
+                action, enc = action.reshape(self.n).to(torch.float64).contiguous(), abi.FTL_ACTION_TURN
+            self._keep_action = action
+        elif action.dtype != torch.float64 or not action.is_contiguous() or tuple(action.shape) != (self.n, 2):
+            raise ValueError("action must be a contiguous float64 [n_envs, 2] tensor on %s" % self.device)
+        _lib.check(self.lib.ftl_step_encoded(self.h, action.data_ptr(), enc, C.byref(self._out), flags, self._stream()), self.lib)
         if check_errors:
-            self.raise_on_errors()
+            self.raise_on_errors(live_errors)
         return self.obs_num, self.lasers, self.reward, self.done, self.status
 
     # ------------------------------------------------------------------ episode metrics / error report
@@ -221,12 +242,12 @@ class VecGame:
 
     def kernel_times(self):
         """Average per-kernel duration in microseconds over the steps timed since the last call:
-        ``dict(frames_us, rays_us, regroup_us, steps)`` (frames includes the v1 tracker's kernel when the config has one; regroup =
-        everything after the ray kernel: ftl_aux_kernel for configs with row-f3 sensors + both regroup kernels, averaged over ALL steps)."""
-        ms, n = (C.c_double * 3)(), C.c_int32()
+        ``dict(frames_us, rays_us, aux_us, regroup_us, steps)`` (frames includes the v1 tracker's kernel when the config has one; aux =
+        ftl_aux_kernel of configs with row-f3 sensors; regroup = both regroup kernels, averaged over ALL steps)."""
+        ms, n = (C.c_double * 4)(), C.c_int32()
         _lib.check(self.lib.ftl_kernel_times(self.h, C.byref(ms), C.byref(n)), self.lib)
         k = max(n.value, 1)
-        return dict(frames_us=ms[0] / k * 1e3, rays_us=ms[1] / k * 1e3, regroup_us=ms[2] / k * 1e3, steps=n.value)
+        return dict(frames_us=ms[0] / k * 1e3, rays_us=ms[1] / k * 1e3, aux_us=ms[2] / k * 1e3, regroup_us=ms[3] / k * 1e3, steps=n.value)
 
     def error_report(self):
         """(number of envs whose sticky error word is set, OR of the FTL_ERR_* bits) -- the conditions under which a
@@ -236,9 +257,21 @@ class VecGame:
         n, bits = self._errors.tolist()
         return int(n), int(bits)
 
-    def raise_on_errors(self):
-        """The exception the reference would have raised (or FtlError for a capacity overflow) if any env reported one."""
-        n, bits = self.error_report()
+    def raise_on_errors(self, live=False):
+        """The exception the reference would have raised (or FtlError for a capacity overflow) if any env reported one.
+        ``live=True`` looks at the error words of the episodes in progress (``FTL_EI_ERROR``, cleared by reset like the sensors the
+        reference's reset() rebuilds) instead of the sticky words that survive resets: what a caller that handles the exception and
+        resets -- the single-env facade -- needs."""
+        if live:
+            w = self.state_field("env_int")[:, abi.EI_ERROR]
+            bad = w != 0
+            n = int(bad.sum().item())
+            bits = 0
+            if n:
+                for v in w[bad].unique().tolist():
+                    bits |= int(v)
+        else:
+            n, bits = self.error_report()
         if bits:
             raise error_for_bits(bits, n)
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FTL_ABI_VERSION 2
+#define FTL_ABI_VERSION 3
 #define FTL_MAX_BEARS 6   /* robots per env = 2 + bears <= 8 (one lane each in a group of the frame kernel); bears 5, 7, .. of
                              move_bear_v4 draw their way-points from `random` every frame (ENV:750-754): ftl_rand_range below */
 #define FTL_MAX_LASERS 4
@@ -57,6 +57,7 @@ enum { FTL_LEADER_MOVING = 0, FTL_LEADER_CRASH = 1, FTL_LEADER_FINISHED = 2 };
 #define FTL_ERR_TRACKER_SEED 8u       /* SEN:264-297: fewer than 2 seed points / popleft on empty corridor */
 #define FTL_ERR_HIST1_OVERFLOW 16u    /* v1 tracker history longer than hist1_cap */
 #define FTL_ERR_LIDAR_OVERFLOW 32u    /* more than 128 objects within range of a LaserSensor: the extra ones were ignored */
+#define FTL_ERR_BAD_ACTION 64u        /* ftl_step_encoded: a Discrete(5) action outside 0..4 (reference: KeyError at ENV:922); stepped as action 2 */
 
 /* robot kinematic limits, px/frame and deg/frame (ENV:330-357, 556-566, 704-714; CLS:59-105) */
 typedef struct ftl_robot_params {
@@ -229,11 +230,15 @@ typedef struct ftl_scen_params {
     int32_t multiple_end_points, path_finding_iterations;
     int32_t bridge_gap, bridge_width;     /* bridge_size[0], bridge_size[1] (ENV:617-620) */
     int32_t trajectory_saving_period;
-    int32_t planner;                      /* path_finding_algorythm: 0 "dstar" (ENV:1493-1612), 1 "astar" (ENV:1632-1711 on utils/astar.py) */
+    int32_t planner;                      /* path_finding_algorythm: 0 "dstar" (ENV:1493-1612), 1 "astar" (ENV:1632-1711 on utils/astar.py);
+                                             2: the caller-supplied `trajectory=` of the constructor (ENV:229, 469-470): no finish point is drawn, no
+                                             planner runs, every scenario gets fixed_route */
     double  min_distance, max_distance;   /* pixels */
     double  leader_pos_epsilon, leader_margin;
     double  leader_w, leader_h;           /* the float pixel sizes the reference keeps on the robot (ENV:352-353, CLS:104-105) */
     double  leader_max_speed;             /* px/frame */
+    const double* fixed_route;            /* planner 2: [fixed_route_len][2] way-points (HOST pointer), else NULL */
+    int32_t fixed_route_len, _pad;
 } ftl_scen_params;
 
 /* per-scenario status bits written by ftl_generate_scenarios */
@@ -307,6 +312,15 @@ int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const
 /* step(action) (ENV:908-945) for all envs: action[n][2] = (speed px/frame, signed rotation deg/frame) as f64. */
 int ftl_step(ftl_handle* h, const double* action, const ftl_outputs* out, uint32_t flags, void* stream);
 
+/* step(action) for the two other action spaces of the constructor (ENV:358-378), decoded on the device exactly as ENV:909-925 does:
+ *   FTL_ACTION_BOX2      action = f64 [n][2]  (speed, signed rotation)                                   -- the same as ftl_step
+ *   FTL_ACTION_DISCRETE  action = int32 [n]   index k of Discrete(5) -> (follower.max_speed, discrete_rotation_speed_to_value[k]) with the
+ *                                 table {-max_rot, -max_rot/2, 0, max_rot/2, max_rot} of ENV:362-367 (discrete_action_space=True)
+ *   FTL_ACTION_TURN      action = f64 [n]     Box(1) rotation -> (0.25, rotation): np.concatenate([[0.25], action]) of ENV:924-925
+ *                                 (constant_follower_speed=True; the speed command of ENV:910-911 is overwritten by ENV:927) */
+enum { FTL_ACTION_BOX2 = 0, FTL_ACTION_DISCRETE = 1, FTL_ACTION_TURN = 2 };
+int ftl_step_encoded(ftl_handle* h, const void* action, int32_t encoding, const ftl_outputs* out, uint32_t flags, void* stream);
+
 /* ---- episode metrics + error report (ENV:941-944 reports overall_reward / step_count at done) --------
  * Every env slot accumulates, at the step in which an episode ends (done set by this step; under FTL_STEP_AUTO_RESET
  * before the slot is re-initialised), the vector below in its "ep_stats" state field (f64[FTL_N_METRICS] per env).
@@ -327,9 +341,9 @@ enum { FTL_M_EPISODES = 0,   /* finished episodes */
 int ftl_episode_metrics(ftl_handle* h, double* dev_metrics, int32_t* dev_errors, uint32_t flags, void* stream);
 
 /* ---- measurement hook (bench.py): per-kernel durations from HIP events on the launch stream ------------------------------
- * While enabled every ftl_step records events around its launches (frame kernel, ray kernel, the two regroup kernels);
+ * While enabled every ftl_step records events around its launches (frame kernel, ray kernel, ftl_aux_kernel, the two regroup kernels);
  * ftl_kernel_times synchronises and returns the SUM of the durations in milliseconds since the last call as
- * ms[3] = {frames, rays, regroup} and the number of steps they cover.  At most 512 steps are held; not available in the
+ * ms[4] = {frames (+ the v1 tracker's kernel), rays, aux (row-f3 sensors; ~0 without them), regroup} and the number of steps they cover.  At most 512 steps are held; not available in the
  * two-stream mode (returns FTL_E_UNSUPPORTED).  Off by default: the events cost a few microseconds per step. */
 int ftl_kernel_timing(ftl_handle* h, int32_t enable);
 int ftl_kernel_times(ftl_handle* h, double* ms, int32_t* n_steps);

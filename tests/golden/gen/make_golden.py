@@ -184,6 +184,29 @@ CONFIGS = {
         ("LeaderCorridor_lasers_all", dict(SENSORS_B["LeaderCorridor_lasers_all"])),
         ("FollowerInfo", {"sensor_class": "FollowerInfo"}),
         ("LeaderCorridor_lasers_obstacles", dict(SENSORS_B["LeaderCorridor_lasers_obstacles"], pad_sectors=True))])), post=None),
+    # ---- constructor switches of the step path that no other config turns on (round 3) --------------------------------------------
+    # config N: TestGameNEAT (ENV:2125-2129, "Test-Game-Neat-v0"): Discrete(5) actions decoded by ENV:360-367, 918-922, no rocks
+    # (add_obstacles=False, ENV:322-323, 464-465), default three bears, no sensors.  "action": what Runner.step hands to Game.step.
+    # With the default D* planner the reference's reset() raises AttributeError ('Game' object has no attribute 'obstacles1', ENV:1501:
+    # generate_trajectory_dstar reads the bridge walls that _create_obstacles never made) -- so the registered ids
+    # "Test-Game-Neat-v0" and "Test-Cont-Env-Auto-Follow-no-obstacles-v0" cannot reset; A* guards that code (ENV:1666).
+    "N": dict(kwargs=dict(add_obstacles=False, discrete_action_space=True, path_finding_algorythm="astar",
+                          early_stopping={"max_distance_coef": 1.2, "low_reward": -100}), post=None, action="discrete"),
+    # constant_follower_speed (ENV:368-372, 910-911, 924-925): Box(1) action = rotation only, speed command 0.25 px/frame
+    "B_cfs": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B, constant_follower_speed=True), post=None, action="turn"),
+    # ignore_follower_collisions (ENV:960): the follower drives through rocks and robots, no crash
+    "B_nocoll": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B, ignore_follower_collisions=True), post=None),
+    # aggregate_reward (ENV:1136-1141): step() returns overall_reward instead of the last frame's reward
+    "B_agg": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B, aggregate_reward=True), post=None),
+    # add_obstacles=False with the sensors of B (TestGameBaseAlgoNoObst, ENV:2109-2112): the static list is empty
+    "B_noobst": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B, add_obstacles=False, path_finding_algorythm="astar",
+                                 early_stopping={"max_distance_coef": 1.2, "low_reward": -100}), post=None),
+    # multiple_end_points (ENV:470-481, 1552-1592): three finish points, three D* legs chained into one route
+    "B_mep": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B, multiple_end_points=True), post=None),
+    # caller-supplied trajectory= (ENV:229, 469-470): no finish point, no planner; the leader heads for trajectory[1]
+    "B_traj": dict(kwargs=dict(bear_number=1, follower_sensors=SENSORS_B,
+                               trajectory=[(1400, 500), (1150, 500), (900, 500), (750, 500), (600, 500), (400, 420), (250, 300), (120, 200)]),
+                   post=None),
 }
 
 
@@ -277,7 +300,15 @@ class Runner:
         return obs
 
     def step(self, action):
+        """``action`` = the decoded (speed, rotation) pair for the Box(2) configs; the raw action (an int of Discrete(5) / the rotation
+        of Box(1)) for configs with an "action" kind -- handed to Game.step in the form a gym policy would produce it."""
+        kind = self.cfg.get("action")
         with contextlib.redirect_stdout(io.StringIO()):
+            if kind == "discrete":
+                k = int(action)
+                return self.game.step(np.array([[k]]) if k % 2 else k)       # both accepted forms (ENV:919-921)
+            if kind == "turn":
+                return self.game.step(np.array([action], dtype=np.float32))   # Box(shape=(1,), dtype=float32), ENV:368-372
             return self.game.step((float(action[0]), float(action[1])))
 
 
@@ -387,6 +418,18 @@ def random_action(g, rng):
     return (float(v), w)
 
 
+def ram_action(g, rng, statics_only=False):
+    """Full speed at the nearest obstacle rect or the leader (episodes of ignore_follower_collisions must drive THROUGH things)."""
+    f = g.follower
+    objs = [o for o in g.game_object_list if o is not f and not (statics_only and o is g.leader)] + ([] if statics_only else list(g.game_dynamic_list))
+    fx, fy = float(f.position[0]), float(f.position[1])
+    tgt = min(objs, key=lambda o: math.hypot(o.rectangle.centerx - fx, o.rectangle.centery - fy) + (200 if o.rectangle.collidepoint(fx, fy) else 0))
+    want = math.degrees(math.atan2(tgt.rectangle.centery - fy, tgt.rectangle.centerx - fx)) % 360.0
+    err = (want - float(f.direction) + 540.0) % 360.0 - 180.0
+    w = max(-f.max_rotation_speed, min(f.max_rotation_speed, err * 0.3 + 0.05 * rng.normal() * f.max_rotation_speed))
+    return (float(f.max_speed), float(w))
+
+
 def sensor_prev_wrapper(g):
     """The reference's own ContinuousObserveModifier_sensorPrev (utils/wrappers.py:169-221) around the Game, or None when its
     constructor cannot run on this sensor dict (it indexes sensor_config["sensor_class"] / ["pad_sectors"] unconditionally)."""
@@ -421,7 +464,7 @@ def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_do
     if wrap is not None:      # observation() is a pure function of the obs dict (+ the sensors' laser_length)
         out["reset:wrap_sensorPrev"] = np.asarray(wrap.observation(obs0)).copy()
     rng = np.random.default_rng(1000 + seed)
-    acts, rews, dones, infos = [], [], [], []
+    acts, rews, dones, infos, raws = [], [], [], [], []
     obs_rows = {}
     dbg_rows = {}
     after_done = 0
@@ -432,11 +475,26 @@ def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_do
             a = chase_action(g, rng, 0.5)
         elif policy == "random":
             a = random_action(g, rng)
+        elif policy in ("ram", "ram_rocks"):
+            a = ram_action(g, rng, policy == "ram_rocks")
         elif policy == "straight":
             a = (0.225 * g.follower.max_speed / 0.25, 0.0)
         else:
             raise ValueError(policy)
-        obs, rew, done, info = r.step(a)
+        kind = r.cfg.get("action")
+        if kind == "discrete":                  # nearest entry of the Discrete(5) table (ENV:362-367); random policy: any entry
+            table = g.discrete_rotation_speed_to_value
+            k = int(rng.integers(5)) if policy == "random" else min(table, key=lambda i: abs(table[i] - a[1]))
+            raws.append(k)
+            obs, rew, done, info = r.step(k)
+            a = (float(g.follower.max_speed), float(table[k]))       # what ENV:922 turns it into
+        elif kind == "turn":
+            w = np.float32(a[1])
+            raws.append(float(w))
+            obs, rew, done, info = r.step(w)
+            a = (0.25, float(w))                                       # np.concatenate([[0.25], action]), ENV:924-925
+        else:
+            obs, rew, done, info = r.step(a)
         acts.append(a)
         rews.append(float(rew))
         dones.append(bool(done))
@@ -453,6 +511,8 @@ def run_episode(config_name, seed, policy, n_steps, debug_every=1, stop_after_do
             if after_done >= stop_after_done:  # the reference keeps simulating after done (ENV:935-936)
                 break
     out["actions"] = np.array(acts, dtype=np.float64)
+    if raws:
+        out["actions_raw"] = np.array(raws, dtype=np.int32 if r.cfg.get("action") == "discrete" else np.float32)
     out["reward"] = np.array(rews, dtype=np.float64)
     out["done"] = np.array(dones, dtype=np.uint8)
     out["info"] = np.array(infos, dtype=np.uint8)
@@ -519,6 +579,20 @@ EPISODES = [
     ("F_s1_chase", "F", 1, "chase", 120),
     ("F_s6_random", "F", 6, "random", 60),
     ("F_s7_chase", "F", 7, "chase_noisy", 100),
+    ("N_s3_chase", "N", 3, "chase", 200),
+    ("N_s8_random", "N", 8, "random", 120),
+    ("Bcfs_s2_chase", "B_cfs", 2, "chase", 150),
+    ("Bcfs_s9_random", "B_cfs", 9, "random", 100),
+    ("Bnocoll_s4_ram", "B_nocoll", 4, "ram_rocks", 300),
+    ("Bnocoll_s7_ram", "B_nocoll", 7, "ram", 200),
+    ("Bagg_s2_chase", "B_agg", 2, "chase", 150),
+    ("Bagg_s6_random", "B_agg", 6, "random", 120),
+    ("Bnoobst_s1_chase", "B_noobst", 1, "chase", 300),
+    ("Bnoobst_s5_random", "B_noobst", 5, "random", 120),
+    ("Bmep_s2_chase", "B_mep", 2, "chase", 520),
+    ("Bmep_s11_noisy", "B_mep", 11, "chase_noisy", 200),
+    ("Btraj_s3_chase", "B_traj", 3, "chase", 400),
+    ("Btraj_s6_random", "B_traj", 6, "random", 150),
 ]
 
 

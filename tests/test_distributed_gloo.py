@@ -56,8 +56,12 @@ def _worker(rank, world, port, q):
     shard.reduce_metrics(m)
     t = torch.tensor([float(sh.n)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # bench.py's plan for the BASELINE workload at this world size: the SAME 65,536 envs in total, summed over the ranks as bench.py does
+    bsh, mode = shard.plan("B", rank, world)
+    tot = torch.tensor([float(bsh.n), float(bsh.lo)], dtype=torch.float64)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     if rank == 0:
-        q.put((m.tolist(), t.item()))
+        q.put((m.tolist(), t.item(), tot.tolist(), mode))
     dist.destroy_process_group()
 
 
@@ -69,6 +73,21 @@ def test_shard_ranges_cover_everything():
             assert max(p.n for p in parts) - min(p.n for p in parts) <= 1
 
 
+def test_bench_plan_is_the_baseline_configuration():
+    """bench.py --gpus N: workload B is BASELINE's 65,536 envs IN TOTAL at every N (config C: 8,192 per GPU at N = 8, strong scaling);
+    workload E is 32,768 per GPU (262,144 at N = 8, weak scaling)."""
+    for w in (1, 2, 4, 8):
+        parts = [shard.plan("B", r, w) for r in range(w)]
+        assert all(m == "strong" for _, m in parts) and sum(s.n for s, _ in parts) == 65536 and parts[0][0].lo == 0
+        assert all(a[0].hi == b[0].lo for a, b in zip(parts, parts[1:])) and all(s.n == 65536 // w for s, _ in parts)
+        e = [shard.plan("E", r, w) for r in range(w)]
+        assert all(m == "weak" for _, m in e) and sum(s.n for s, _ in e) == 32768 * w and all(a[0].hi == b[0].lo for a, b in zip(e, e[1:]))
+    assert shard.plan("B", 3, 8)[0] == shard.Shard(3, 8, 3 * 8192, 4 * 8192)
+    assert shard.plan("B", 1, 2, envs_per_gpu=4096) == (shard.Shard(1, 2, 4096, 8192), "weak")       # weak scaling behind a flag
+    assert shard.plan("B", 0, 1, total_envs=8192)[0].n == 8192 and shard.plan("D", 0, 1)[0].n == 4096
+    assert shard.plan("E", 1, 2, scaling="strong")[0] == shard.Shard(1, 2, 16384, 32768)
+
+
 def test_two_rank_gloo_matches_single_process():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -78,11 +97,12 @@ def test_two_rank_gloo_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, nmax = q.get(timeout=300)
+    got, nmax, btot, bmode = q.get(timeout=300)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     ref = _run_shard(0, N_TOTAL).tolist()
     assert got == ref, (got, ref)
     assert nmax == N_TOTAL // 2
+    assert btot == [65536.0, 32768.0] and bmode == "strong"     # bench.py --gpus 2: total_envs == 65,536, rank 1 starts at env 32,768
     assert ref[0] >= 1, "the sample should finish at least one episode so that the metrics are non-trivial"

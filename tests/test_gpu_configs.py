@@ -79,6 +79,14 @@ def _corner_grazes(env, cfg, bad):
     return out
 
 
+# Budget of the knife-edge waivers: every ray reading compared with the oracle and every one excused as a corner
+# graze is counted over the whole test session; the running ratio is asserted after every comparison and reported at the end of the
+# session (tests/test_gpu_fuzz.py::test_zz_waiver_budget).  A graze shows up in up to max_prev_obs rows while its snapshot ages, so the
+# bound has a constant part of two such events.
+WAIVERS = dict(readings=0, corner=0, radar_env_steps=0, env_steps=0, radar_worst=0.0)
+CORNER_BUDGET = 1e-4
+
+
 def _compare_with_oracle(env, ora, cfg, tag):
     num = env.obs_num.cpu().numpy(); las = env.lasers.cpu().numpy()
     assert np.array_equal(env.done.cpu().numpy(), ora.done), (tag, "done")
@@ -88,9 +96,13 @@ def _compare_with_oracle(env, ora, cfg, tag):
     assert np.array_equal(env.target.cpu().numpy(), ora.target), (tag, "target")
     L = cfg.lasers_len
     bad = ~close(las[:, :L], ora.lasers[:, :L])
+    WAIVERS["readings"] += int(sum(l.history * l.width for l in cfg.lasers)) * env.n
     if bad.any():
-        bad &= ~_corner_grazes(env, cfg, bad)
+        graze = _corner_grazes(env, cfg, bad)
+        WAIVERS["corner"] += int((bad & graze).sum())
+        bad &= ~graze
     assert not bad.any(), (tag, "lasers", np.argwhere(bad)[:5], np.abs(las[:, :L] - ora.lasers[:, :L]).max())
+    assert WAIVERS["corner"] <= CORNER_BUDGET * WAIVERS["readings"] + 2 * abi.FTL_MAX_LASERS * 12, (tag, "corner-graze waivers over budget", WAIVERS)
     ri = env.state_field("rb_int").cpu().numpy().reshape(env.n, cfg.n_robots, abi.RI_COUNT)
     assert np.array_equal(ri[:, :, :6], ora.robot_ints()), (tag, "hitboxes")
 

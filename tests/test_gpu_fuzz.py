@@ -7,9 +7,11 @@ import numpy as np
 import pytest
 import torch
 
-from continiousenvironment_follower_leader_amd import make_config
+from continiousenvironment_follower_leader_amd import abi, make_config
 from oracle_batch import OracleBatch, pool_scenarios
-from test_gpu_configs import _actions, _compare_with_oracle, _vec
+from test_gpu_configs import CORNER_BUDGET, WAIVERS, _actions, _compare_with_oracle, _vec
+
+RADAR_BUDGET = 0.05      # env-steps per config with a radar reading excused as a sector-boundary knife edge (tightened after measuring)
 
 pytestmark = pytest.mark.gpu
 
@@ -174,5 +176,30 @@ def test_random_config_matches_oracle(seed):
             err_seen |= ora.counters()[2]
     rep = env.error_report()             # sticky: the bits of every episode since the handle was created
     assert rep[0] == int((err_seen != 0).sum()) and rep[1] == int(np.bitwise_or.reduce(err_seen)), (seed, rep, np.unique(err_seen))
-    assert stats[0] <= 0.05 * stats[1], (seed, stats)        # knife edges are the exception
+    # capacity overflows of the batched state are never part of a legitimate comparison: both sides would share the truncation
+    cap_bits = abi.FTL_ERR_TRAJ_OVERFLOW | abi.FTL_ERR_CORR_OVERFLOW | abi.FTL_ERR_HIST1_OVERFLOW | abi.FTL_ERR_LIDAR_OVERFLOW
+    assert rep[1] & cap_bits == 0, (seed, hex(rep[1]))
+    WAIVERS["radar_env_steps"] += stats[0]; WAIVERS["env_steps"] += stats[1]
+    WAIVERS["radar_worst"] = max(WAIVERS["radar_worst"], stats[0] / max(stats[1], 1))
+    assert stats[0] <= RADAR_BUDGET * stats[1], (seed, stats)        # knife edges are the exception
     env.close()
+
+
+def test_zz_waiver_budget():
+    """Runs after the oracle comparisons of tests/test_gpu_configs.py and of this file: the session totals of the two knife-edge waivers
+     against their budgets, printed and written to gpurun_out/waivers.json."""
+    import json
+    import os
+    w = dict(WAIVERS)
+    w["corner_fraction"] = w["corner"] / max(w["readings"], 1)
+    w["radar_fraction"] = w["radar_env_steps"] / max(w["env_steps"], 1)
+    print("waivers:", json.dumps(w))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/waivers.json", "w") as fh:
+            json.dump(w, fh)
+    except OSError:
+        pass
+    assert w["readings"] > 0
+    assert w["corner"] <= CORNER_BUDGET * w["readings"] + 2 * abi.FTL_MAX_LASERS * 12, w
+    assert w["radar_env_steps"] <= 0.5 * RADAR_BUDGET * max(w["env_steps"], 1) + 5, w
