@@ -8,7 +8,7 @@ from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, Vec
 import bench
 z = np.load(GOLDEN + "/pool_B.npz"); meta = json.loads(str(z["meta"]))
 cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=int(z["route_len"].max()))
-n = 65536
+n = int(os.environ.get("FTL_DIAG_N", "65536"))
 env = VecGame(n, device="cuda:0", config=cfg); pool = ScenarioPool.from_npz(cfg, GOLDEN + "/pool_B.npz", "cuda:0"); env.load_scenarios(pool)
 GROUP = int(os.environ.get("FTL_DIAG_GROUP", "1"))      # >1: make every GROUP consecutive envs identical (no divergence inside a wavefront)
 env.reset(((torch.arange(n) // GROUP) % pool.n).to(torch.int32))

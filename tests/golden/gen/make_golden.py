@@ -582,7 +582,7 @@ EPISODES = [
     ("N_s3_chase", "N", 3, "chase", 200),
     ("N_s8_random", "N", 8, "random", 120),
     ("Bcfs_s2_chase", "B_cfs", 2, "chase", 150),
-    ("Bcfs_s9_random", "B_cfs", 9, "random", 100),
+    ("Bcfs_s5_random", "B_cfs", 5, "random", 100),
     ("Bnocoll_s4_ram", "B_nocoll", 4, "ram_rocks", 300),
     ("Bnocoll_s7_ram", "B_nocoll", 7, "ram", 200),
     ("Bagg_s2_chase", "B_agg", 2, "chase", 150),

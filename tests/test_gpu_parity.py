@@ -74,8 +74,12 @@ def test_hip_matches_reference_episode(name):
 
     check("reset", None)
     acts = z["actions"]
+    raw = z["actions_raw"] if "actions_raw" in z else None      # Discrete(5) indices / Box(1) rotations: decoded on the device (ftl_step_encoded)
     for t in range(len(acts)):
-        a = torch.tensor(np.tile(acts[t], (n, 1)), dtype=torch.float64, device="cuda:0")
+        if raw is None:
+            a = torch.tensor(np.tile(acts[t], (n, 1)), dtype=torch.float64, device="cuda:0")
+        else:
+            a = torch.full((n,), raw[t].item(), dtype=torch.int32 if raw.dtype == np.int32 else torch.float64, device="cuda:0")
         env.step(a)
         check("obs", t)
         rew = env.reward.cpu().numpy(); done = env.done.cpu().numpy(); st = env.status.cpu().numpy()
