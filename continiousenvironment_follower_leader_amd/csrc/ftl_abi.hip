@@ -237,6 +237,22 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
                            + rects * 8 + 32                   /* facing-edge list (u16 x 4 per rect) + edge counters */
                            + (size_t)FTL_PAIR_CAP * 2 + 16);  /* candidate list of phase 3 */
     }
+    {   // frame kernel LDS: near lists + their counters | frame records (one byte per env and frame) | pending position checks | slot -> env
+        const int epw = FTL_WAVE / (P.R <= 4 ? 4 : 8);
+        const int f_max = cfg->rand_fps_hi > 0 ? cfg->rand_fps_hi - 1 : cfg->frames_per_step;
+        // The searches of frames 1.. wait for the end of the step when the step is short enough for their items to sit in LDS and the frame
+        // count is the same for every env; otherwise every frame's searches run right after it (one item per env at most).
+        const char* dv = getenv("FTL_DEFER");
+        P.fr_defer = (cfg->rand_fps_hi == 0 && f_max >= 2 && f_max <= 16 && cfg->traj_cap <= 65535 && !(dv && dv[0] == '0')) ? 1 : 0;
+        if (cfg->traj_cap > 65535 || f_max > 4095) { delete h; return fail(FTL_E_INVALID, "traj_cap above 65535 or more than 4095 frames per step"); }
+        size_t o = align_up((size_t)epw * cfg->n_static * 16 + (size_t)epw * 4 + 32, 16);
+        P.fr_rec_stride = (int)align_up((size_t)f_max, 16);
+        P.fr_rec_off = (int)o; o += (size_t)P.fr_rec_stride * epw;
+        P.fr_pend_off = (int)o; o += (size_t)epw * (P.fr_defer ? f_max - 1 : 1) * 16;
+        P.fr_env_off = (int)o; o += (size_t)epw * 4 + 16;
+        P.fr_lds = (int)o;
+        if (o > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "the frame kernel needs more than 64 KiB of LDS per wavefront (static rects x frames per step)"); }
+    }
     auto debug_pad = [](const char* name) { const char* v = getenv(name); const int p = v ? atoi(v) : 0; return p < 0 ? 0 : (p > 48 * 1024 ? 48 * 1024 : p); };
     P.lds_rays += debug_pad("FTL_DEBUG_LDS_PAD_RAYS");      // diagnostic: occupancy of the ray kernel without touching the code
     h->lds_pad = (size_t)debug_pad("FTL_DEBUG_LDS_PAD");
@@ -365,8 +381,7 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         const int count = my_groups * epw0;              // slots of this launch (the tail of the last group may be idle)
         const bool reg = h->P.cfg.n_speed_regime >= 0 || h->P.cfg.n_acc_regime >= 0 || h->P.cfg.rand_fps_hi > 0;
         const int epw = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
-        size_t lds = (size_t)epw * h->P.cfg.n_static * 16 + (size_t)epw * 4 + 32;
-        lds += h->lds_pad;
+        size_t lds = (size_t)h->P.fr_lds + h->lds_pad;
         const dim3 grid((count + epw - 1) / epw), block(FTL_WAVE);
         if (tev) (void)hipEventRecord(tev[0], s);
         if (h->P.R <= 4) {

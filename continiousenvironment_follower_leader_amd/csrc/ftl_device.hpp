@@ -48,6 +48,8 @@ struct FtlRaySensor {
 struct FtlDevParams {
     ftl_config cfg;
     int32_t n_envs, R, lasers_len, total_rays, hmax, lds_rays;
+    int32_t fr_rec_off, fr_rec_stride, fr_pend_off, fr_env_off, fr_defer, fr_lds;   // frame kernel: LDS offsets of the frame records / pending items / slot -> env table
+                                      // (+ the item counter), "the later frames' position searches wait for the end of the step", total dynamic LDS
     int32_t corr_lds_cap;             // corridor points the ray kernel stages in LDS (a power of two <= cfg.corr_cap; a longer window is read in place)
     int32_t pol_off[FTL_MAX_LASERS], pol_width, pol_h;   // fused sensorPrev output: column offset per sensor (-1: not part of it), row width, common history
     // per-env state (views into the caller-owned state buffer), all [n_envs][...]

@@ -542,16 +542,21 @@ __device__ __forceinline__ int g_cache_class(const ftl_config& c, const GCtx& E,
     return fast;
 }
 
+// One frame leaves a one-byte record per env for the tail of frame_step (g_tail) ...
+enum { FR_TOO_CLOSE = 1, FR_IN_BOX = 2, FR_ON_TRACE = 4, FR_COLLISION = 8, FR_LEADER_HIT = 16, FR_LEADER_FINISHED = 32, FR_TOO_FAR = 64,
+       FR_PENDING = 128 };   // FR_PENDING: in box / on trace are still to be searched for (g_resolve)
+// ... and, when its position check needs a search, a pending item: the follower's position, the trajectory length and the green count
+// as that frame saw them (the trajectory only grows, so [0, n) is still there later), the cached point index, frame << 4 | slot
+struct FrPend { float fpx, fpy; unsigned short n, gc, hint, key; };
+
 // REG = the config has leader regimes or random_frames_per_step: compiled apart (their mere presence cost the common kernel 2 %)
 template <int G, bool REG>
-__device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near, float4* s_bb, int& tick,
-                                        double& reward, int& i0, int& i1, int& i2, const bool first) {
+__device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near, int& tick, const bool first, const int f_idx,
+                                        unsigned char* s_rec, const int rec_stride, FrPend* s_pend, int* s_pcnt, bool& pend, int& pend_idx, float& new_ad) {
     const ftl_config& c = P.cfg;
     const int r = E.r;
     const bool act = E.valid && r < P.R;
     FTL_TIC_INIT;
-    E.is_in_box = 0; E.is_on_trace = 0;
-    i0 = FTL_MISSION_IN_PROGRESS; i1 = FTL_AGENT_MOVING; i2 = FTL_LEADER_MOVING;
 
     // the other robots as the follower's collision test and the bears' way-points see them: before anybody moves
     const float lpx0 = gb_f<G, 0>(E.rb.px), lpy0 = gb_f<G, 0>(E.rb.py);
@@ -632,7 +637,6 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     if (steers) steer_to_point(E.rb, L, tx, ty, r == 0, lspeed);
     if (E.leader_finished) {                                   // ENV:1062-1065
         if (r == 0) { command_forward(E.rb, L, 0); command_turn(E.rb, L, 0, 0); }
-        i2 = FTL_LEADER_FINISHED;
     }
     bool moves = act && !(r == 0 && E.leader_finished);
     robot_move(E.rb, L, moves);
@@ -651,9 +655,10 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     if (act && r != 1) fhit |= rects_collide(frx, fry, frw, frh, orx, ory, orw, orh);     // leader / bears where they were
     if (act && r == 1) lhit |= rects_collide(lrx, lry, lrw, lrh, E.rb.rx, E.rb.ry, E.rb.rw, E.rb.rh);   // follower where it is now
     fhit = group_any<G>(fhit); lhit = group_any<G>(lhit);
+    bool f_coll = false;
     if (!c.ignore_follower_collisions) {
         bool out = (double)fpx > (double)c.width || (double)fpy > (double)c.height || fpx < 0.0f || fpy < 0.0f;
-        if (fhit || out) { E.crash = 1; E.done = 1; i0 = FTL_MISSION_FAIL; i1 = FTL_AGENT_CRASH; }
+        f_coll = fhit || out;
     }
     FTL_TIC(0);
     // green zone (ENV:968-969): recomputed when a point was appended
@@ -724,9 +729,10 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     const int Gc = E.green_count, n = E.traj_len;
     // _check_agent_position (ENV:1906-1937).  Its two arg-min searches only feed threshold tests: closest green point
     // within epsilon -> on trace + in box; within max_dev -> in box; otherwise closest point of the WHOLE trajectory
-    // within epsilon -> on trace.  g_range_argmin() returns the reference's arg-min whenever it matters for such a
-    // test; a hint window around the point that was close last frame settles the common on-trace case first.
-#ifndef FTL_ABLATE_AGENT
+    // within epsilon -> on trace.  Most frames settle them from the env's search caches without touching memory (below); the
+    // frames that cannot leave a PENDING item behind and go on: g_position_search() runs for the items of the whole wavefront, sixteen
+    // at a time, after the frame that needs their caches refreshed (the first of a step) and after the last one.
+    int rec = f_coll ? FR_COLLISION : 0;                      // this frame's record for the tail (FR_* bits)
     FTL_PROF(0, E.valid && r == 0, 1);
     // Search caches (exact: they only decide which points have to be looked at).  clr_g / clr_a are lower bounds on the
     // follower's distance to every green point / every trajectory point: a search leaves behind the smallest distance it
@@ -738,125 +744,47 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         float disp = sqrtf(mx * mx + my * my) * 1.000001f + 1e-5f;
         E.clr_g -= disp; E.clr_a -= disp;
     }
+    pend = false;
     if (Gc > 2) {
         FTL_PROF(1, E.valid && r == 0, 1);
-        const double eps = c.leader_pos_epsilon, mdev = c.max_dev;
-        const double far = fmax(mdev, eps);
-        const float4* bb = s_bb;                              // block bounding boxes of this env's trajectory (global memory)
-        const int g_lo = n - 1 - Gc;                           // green points are indices g_lo .. n-2
-        const float eps2_lo = (float)(eps * eps * (1.0 - 1e-5));
         // Refresh ahead of need.  A search is paid by the whole wavefront, whichever env asks for it, so the envs whose
-        // caches would run out somewhere inside this step all search NOW, in the first frame, instead of in different ones.
+        // caches would run out somewhere inside this step all search after the FIRST frame, instead of in different ones.
         bool quiet;
         int fast = g_cache_class(c, E, fpx, fpy, E.fps, first, quiet);
-        FTL_PROF(4, E.valid && r == 0 && first && !quiet && fast == 1, 1); FTL_PROF(5, E.valid && r == 0 && first && !quiet && fast == 2, 1);
-        FTL_PROF(6, E.valid && r == 0 && first && !quiet && fast == 3, 1); FTL_PROF(7, E.valid && r == 0 && first && !quiet && fast == 4, 1);
-        FTL_PROF(12, E.valid && r == 0 && first && fast == 0, 1);
         if (first && !quiet) fast = 0;
         FTL_PROF(2, E.valid && r == 0 && fast != 0, 1);
-        FTL_PROF(8, E.valid && r == 0 && !first && fast == 0 && P.keys && (P.keys[E.env] & 0x3c) == 0, 1);
-        FTL_PROF(9, E.valid && r == 0 && first && fast == 0 && P.keys && (P.keys[E.env] & 0x3c) == 0, 1);
         FTL_PROF(13, E.valid && r == 0 && first && fast == 0, 1);
         FTL_PROF(14, E.valid && r == 0 && !first && fast == 0, 1);
-        FTL_PROF(15, E.valid && r == 0 && first, 1);
-        if (fast == 1) { E.is_on_trace = 1; E.is_in_box = 1; }
-        else if (fast == 2) { E.is_in_box = 1; }
-        else if (fast == 4) { E.is_on_trace = 1; }
+        if (fast == 1) rec |= FR_ON_TRACE | FR_IN_BOX;
+        else if (fast == 2) rec |= FR_IN_BOX;
+        else if (fast == 4) rec |= FR_ON_TRACE;
         else if (fast == 0) {
-        E.n_search += 1;
-        // hint window: 4*G points around the point that was closest last frame, one memory round trip
-        float wbest = __int_as_float(0x7f800000); int widx = 0x7fffffff;      // over the whole window
-        float gbest = __int_as_float(0x7f800000); int gidx = 0x7fffffff;      // over its green members (ties -> higher index)
-        float2 wp = make_float2(0.0f, 0.0f), gp = wp;                         // their coordinates
-        // the green member FARTHEST AHEAD (largest index: the follower is chasing the leader) that is comfortably inside
-        // epsilon: as the next cached point it stays valid about twice as long as the closest one
-        int aidx = -1; float2 ap = wp;
-        const float reach_a = (float)E.fps * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed)) * 1.001f + 1.0f;
-        const float ahead2 = fmaxf((float)eps * 0.99999f - reach_a, 0.0f) * fmaxf((float)eps * 0.99999f - reach_a, 0.0f);
-        {
-            int w0 = E.hint - G; w0 = w0 < 0 ? 0 : w0;                       // a quarter of the window behind the old point, the rest ahead
-            float2 wq[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) wq[k] = tr[min(w0 + k * G + r, n - 1)];        // unguarded loads: issued back to back
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int i = w0 + k * G + r;
-                if (i < n) {
-                    float2 p = wq[k];
-                    float dx = p.x - fpx, dy = p.y - fpy;
-                    float d2 = dx * dx + dy * dy;
-                    if (d2 < wbest) { wbest = d2; widx = i; wp = p; }
-                    if (i >= g_lo && i <= n - 2 && d2 <= gbest) { gbest = d2; gidx = i; gp = p; }
-                    if (i >= g_lo + 4 && i <= n - 2 && d2 < ahead2 && i > aidx) { aidx = i; ap = p; }
-                }
-            }
-#pragma unroll
-            for (int off = G / 2; off >= 1; off >>= 1) {
-                float ov = gx(wbest, off, G); int oi = gx(widx, off, G);
-                float ox = gx(wp.x, off, G), oy = gx(wp.y, off, G);
-                bool take = (ov < wbest) || (ov == wbest && oi < widx);
-                if (take) { wbest = ov; widx = oi; wp.x = ox; wp.y = oy; }
-            }
-#pragma unroll
-            for (int off = G / 2; off >= 1; off >>= 1) {
-                float ov = gx(gbest, off, G); int oi = gx(gidx, off, G);
-                float ox = gx(gp.x, off, G), oy = gx(gp.y, off, G);
-                bool take = (ov < gbest) || (ov == gbest && oi != 0x7fffffff && (gidx == 0x7fffffff || oi > gidx));
-                if (take) { gbest = ov; gidx = oi; gp.x = ox; gp.y = oy; }
-            }
-#pragma unroll
-            for (int off = G / 2; off >= 1; off >>= 1) {
-                int oi = gx(aidx, off, G); float ox = gx(ap.x, off, G), oy = gx(ap.y, off, G);
-                if (oi > aidx) { aidx = oi; ap.x = ox; ap.y = oy; }
-            }
-        }
-        FTL_TIC(8);
-        if (gbest < eps2_lo) {                                 // a green point is within epsilon
-            E.is_on_trace = 1; E.is_in_box = 1;
-            if (aidx >= 0) { E.hint = aidx; E.hx = ap.x; E.hy = ap.y; } else { E.hint = gidx; E.hx = gp.x; E.hy = gp.y; }
-        }
-#ifndef FTL_ABLATE_SEARCH
-        else {
-            float gb2; int gi; float2 q; float skip;
-            FTL_PROF(3, E.valid && r == 0, 1);
-            g_range_argmin<G>(tr, bb, r, fpx, fpy, g_lo, n - 1, (float)(far * far * (1.0 + 1e-5)) + 1e-2f, true, gidx, gbest, gp, gb2, gi, q, skip);
-            E.clr_g = sqrtf(fmaxf(fminf(gb2, skip), 0.0f)) * 0.999999f - 1e-3f;       // every green point is at least this far
-            FTL_TIC(11);
-            bool in_eps = false, in_dev = false;
-            if (gi != 0x7fffffff) {
-                in_eps = euclid_f32_le(fpx, fpy, q.x, q.y, eps);
-                in_dev = !in_eps && euclid_f32_le(fpx, fpy, q.x, q.y, mdev);
-            }
-            FTL_PROF(10, E.valid && r == 0 && in_eps, 1); FTL_PROF(11, E.valid && r == 0 && in_dev, 1);
-            if (in_eps) { E.is_on_trace = 1; E.is_in_box = 1; E.hint = gi; E.hx = q.x; E.hy = q.y; }
-            else if (in_dev) { E.is_in_box = 1; E.is_on_trace = 0; E.hint = gi; E.hx = q.x; E.hy = q.y; }
-            else if (wbest < eps2_lo) { E.is_on_trace = 1; E.is_in_box = 0; E.hint = widx; E.hx = wp.x; E.hy = wp.y; }   // some point is within epsilon
-            else {                                             // closest point of the whole trajectory (ENV:1924-1930)
-                float ab2; int ai; float2 q2; float skip2;
+            E.n_search += 1;
+            pend = E.valid;
+            rec |= FR_PENDING;
 #ifdef FTL_WAVE_TIMES
-                E.dbg_full += 1;
+            if (!first) E.dbg_full += 1;          // (diagnostic: items left for the end of the step)
 #endif
-                g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, widx, wbest, wp, ab2, ai, q2, skip2);
-                E.clr_a = sqrtf(fmaxf(fminf(ab2, skip2), 0.0f)) * 0.999999f - 1e-3f;  // every trajectory point is at least this far
-                if (ai != 0x7fffffff) {
-                    if (euclid_f32_le(fpx, fpy, q2.x, q2.y, eps)) { E.is_on_trace = 1; E.is_in_box = 0; }
-                    E.hint = ai; E.hx = q2.x; E.hy = q2.y;
-                }
+            if (E.valid && r == 0) {                             // the item: everything the search needs of this frame
+                const int k = atomicAdd(s_pcnt, 1);
+                pend_idx = k;
+                FrPend it;
+                it.fpx = fpx; it.fpy = fpy; it.n = (unsigned short)n; it.gc = (unsigned short)Gc; it.hint = (unsigned short)E.hint;
+                it.key = (unsigned short)((f_idx << 4) | E.slot);
+                s_pend[k] = it;
             }
-        }
-#endif
         }
     }
-#endif
     FTL_TIC(2);
-    E.too_close = euclid_f32_le(lpx0, lpy0, fpx, fpy, c.min_distance);
+    if (euclid_f32_le(lpx0, lpy0, fpx, fpy, c.min_distance)) rec |= FR_TOO_CLOSE;
     {   // leader collision (ENV:1068-1072)
         bool out = (double)lpx > (double)c.width || (double)lpy > (double)c.height || lpx < 0.0f || lpy < 0.0f;
-        if (lhit || out) { E.done = 1; i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_CRASH; }
+        if (lhit || out) rec |= FR_LEADER_HIT;
     }
     // ENV:1074-1075 with the deterministic tick: frame k (1-based since reset) sees get_ticks() == k
     const bool append = tick == 0;           // tick == (step_count + 1) % trajectory_saving_period, kept incrementally
     tick = (tick + 1 == c.trajectory_saving_period) ? 0 : tick + 1;
+    new_ad = 3.0e38f;
     if (append) {
         if (E.traj_len < c.traj_cap) {
             if (E.valid && r == 0) {
@@ -870,41 +798,191 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
                 float ax = lpx - fpx, ay = lpy - fpy;
                 float ad = sqrtf(ax * ax + ay * ay) * 0.999999f - 1e-3f;
                 E.clr_g = fminf(E.clr_g, ad); E.clr_a = fminf(E.clr_a, ad);
+                new_ad = ad;                 // (a search of this frame that refreshes the bounds afterwards has not seen the point)
             }
             E.traj_len += 1;
         } else E.error |= FTL_ERR_TRAJ_OVERFLOW;
     }
-    if (E.leader_finished && E.is_in_box) {                 // ENV:1077-1087
+    if (c.has_max_distance_coef) {                          // ENV:1099-1107, the distance part (the tail applies the warm-start gate)
+        float dx = fpx - lpx, dy = fpy - lpy;
+        float nrm = sqrtf(dx * dx + dy * dy);
+        if (nrm > (float)(c.max_distance * c.max_distance_coef)) rec |= FR_TOO_FAR;
+    }
+    if (E.leader_finished) rec |= FR_LEADER_FINISHED;
+    E.step_count += 1;
+    if (E.valid && r == 0) s_rec[E.slot * rec_stride + f_idx] = (unsigned char)rec;
+    FTL_TIC(3);
+}
+
+// The searches of _check_agent_position for one pending (env, frame) item, by one group of G lanes (any group: everything comes from
+// the item).  Returns FR_IN_BOX | FR_ON_TRACE; hint / hx / hy / clr_g / clr_a are the env's search caches as this search leaves them.
+template <int G>
+__device__ __forceinline__ int g_position_search(const ftl_config& c, const float2* tr, const float4* bb, const int r, const float fpx, const float fpy,
+                                                 const int n, const int Gc, const int fps, int& hint, float& hx, float& hy, float& clr_g, float& clr_a) {
+    const double eps = c.leader_pos_epsilon, mdev = c.max_dev;
+    const double far = fmax(mdev, eps);
+    const int g_lo = n - 1 - Gc;                           // green points are indices g_lo .. n-2
+    const float eps2_lo = (float)(eps * eps * (1.0 - 1e-5));
+    int bits = 0;
+    // hint window: 4*G points around the point that was closest last time, one memory round trip
+    float wbest = __int_as_float(0x7f800000); int widx = 0x7fffffff;      // over the whole window
+    float gbest = __int_as_float(0x7f800000); int gidx = 0x7fffffff;      // over its green members (ties -> higher index)
+    float2 wp = make_float2(0.0f, 0.0f), gp = wp;                         // their coordinates
+    // the green member FARTHEST AHEAD (largest index: the follower is chasing the leader) that is comfortably inside
+    // epsilon: as the next cached point it stays valid about twice as long as the closest one
+    int aidx = -1; float2 ap = wp;
+    const float reach_a = (float)fps * (float)fmax(fabs(c.follower.max_speed), fabs(c.follower.min_speed)) * 1.001f + 1.0f;
+    const float ahead2 = fmaxf((float)eps * 0.99999f - reach_a, 0.0f) * fmaxf((float)eps * 0.99999f - reach_a, 0.0f);
+    {
+        int w0 = hint - G; w0 = w0 < 0 ? 0 : w0;                         // a quarter of the window behind the old point, the rest ahead
+        float2 wq[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) wq[k] = tr[min(w0 + k * G + r, n - 1)];        // unguarded loads: issued back to back
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int i = w0 + k * G + r;
+            if (i < n) {
+                float2 p = wq[k];
+                float dx = p.x - fpx, dy = p.y - fpy;
+                float d2 = dx * dx + dy * dy;
+                if (d2 < wbest) { wbest = d2; widx = i; wp = p; }
+                if (i >= g_lo && i <= n - 2 && d2 <= gbest) { gbest = d2; gidx = i; gp = p; }
+                if (i >= g_lo + 4 && i <= n - 2 && d2 < ahead2 && i > aidx) { aidx = i; ap = p; }
+            }
+        }
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            float ov = gx(wbest, off, G); int oi = gx(widx, off, G);
+            float ox = gx(wp.x, off, G), oy = gx(wp.y, off, G);
+            bool take = (ov < wbest) || (ov == wbest && oi < widx);
+            if (take) { wbest = ov; widx = oi; wp.x = ox; wp.y = oy; }
+        }
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            float ov = gx(gbest, off, G); int oi = gx(gidx, off, G);
+            float ox = gx(gp.x, off, G), oy = gx(gp.y, off, G);
+            bool take = (ov < gbest) || (ov == gbest && oi != 0x7fffffff && (gidx == 0x7fffffff || oi > gidx));
+            if (take) { gbest = ov; gidx = oi; gp.x = ox; gp.y = oy; }
+        }
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            int oi = gx(aidx, off, G); float ox = gx(ap.x, off, G), oy = gx(ap.y, off, G);
+            if (oi > aidx) { aidx = oi; ap.x = ox; ap.y = oy; }
+        }
+    }
+    if (gbest < eps2_lo) {                                 // a green point is within epsilon
+        bits = FR_ON_TRACE | FR_IN_BOX;
+        if (aidx >= 0) { hint = aidx; hx = ap.x; hy = ap.y; } else { hint = gidx; hx = gp.x; hy = gp.y; }
+    } else {
+        float gb2; int gi; float2 q; float skip;
+        g_range_argmin<G>(tr, bb, r, fpx, fpy, g_lo, n - 1, (float)(far * far * (1.0 + 1e-5)) + 1e-2f, true, gidx, gbest, gp, gb2, gi, q, skip);
+        clr_g = sqrtf(fmaxf(fminf(gb2, skip), 0.0f)) * 0.999999f - 1e-3f;       // every green point is at least this far
+        bool in_eps = false, in_dev = false;
+        if (gi != 0x7fffffff) {
+            in_eps = euclid_f32_le(fpx, fpy, q.x, q.y, eps);
+            in_dev = !in_eps && euclid_f32_le(fpx, fpy, q.x, q.y, mdev);
+        }
+        if (in_eps) { bits = FR_ON_TRACE | FR_IN_BOX; hint = gi; hx = q.x; hy = q.y; }
+        else if (in_dev) { bits = FR_IN_BOX; hint = gi; hx = q.x; hy = q.y; }
+        else if (wbest < eps2_lo) { bits = FR_ON_TRACE; hint = widx; hx = wp.x; hy = wp.y; }   // some point is within epsilon
+        else {                                             // closest point of the whole trajectory (ENV:1924-1930)
+            float ab2; int ai; float2 q2; float skip2;
+            g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, widx, wbest, wp, ab2, ai, q2, skip2);
+            clr_a = sqrtf(fmaxf(fminf(ab2, skip2), 0.0f)) * 0.999999f - 1e-3f;  // every trajectory point is at least this far
+            if (ai != 0x7fffffff) {
+                if (euclid_f32_le(fpx, fpy, q2.x, q2.y, eps)) bits = FR_ON_TRACE;
+                hint = ai; hx = q2.x; hy = q2.y;
+            }
+        }
+    }
+    return bits;
+}
+
+// The pending items of the wavefront.  Two modes.  own >= 0 / -1 (per group): the group searches for its OWN env's item of the frame
+// that just ran (index `own`, -1 = none) and takes the refreshed search caches home (hint .. clr_a by reference; a bound the search did
+// not touch stays negative).  Otherwise (`spread`): items [0, cnt) go to the groups sixteen at a time, whichever env they belong to --
+// the searches of the later frames of a step, whose caches nobody waits for.  The result bits replace FR_PENDING in the frame records.
+template <int G>
+__device__ __forceinline__ void g_resolve(const FtlDevParams& P, const GCtx& E, const FrPend* s_pend, unsigned char* s_rec, const int rec_stride, const int* s_env,
+                                          const int cnt, const bool spread, const int own, int& hint, float& hx, float& hy, float& clr_g, float& clr_a) {
+    constexpr int EPW = FTL_WAVE / G;
+    const ftl_config& c = P.cfg;
+    for (int base = 0; base < (spread ? cnt : 1); base += EPW) {      // wave-uniform trip count
+        const int k = spread ? base + E.slot : own;
+        if (k >= 0 && k < cnt) {                                     // group-uniform
+            const FrPend it = s_pend[k];
+            const int oslot = it.key & 15, frame = it.key >> 4, env = s_env[oslot];
+            const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)env * c.traj_cap * 2);
+            const float4* bb = reinterpret_cast<const float4*>(P.traj_bb) + (size_t)env * (c.traj_cap / FTL_TRAJ_BLOCK);
+            hint = it.hint; hx = 3.0e38f; hy = 3.0e38f; clr_g = -1.0f; clr_a = -1.0f;
+            const int bits = g_position_search<G>(c, tr, bb, E.r, it.fpx, it.fpy, (int)it.n, (int)it.gc, spread ? c.frames_per_step : E.fps, hint, hx, hy, clr_g, clr_a);
+            if (E.r == 0) {
+                unsigned char* rp = s_rec + oslot * rec_stride + frame;
+                *rp = (unsigned char)((*rp & ~(FR_PENDING | FR_IN_BOX | FR_ON_TRACE)) | bits);
+            }
+        }
+    }
+}
+
+// The constants of the tail, loaded once per wavefront and made opaque to the compiler: left as loads from the parameter block they are
+// re-loaded where they are used (there are no registers to keep them in across the frame loop), and the reward code becomes a chain of
+// ten `s_load; s_waitcnt` per frame.  The readfirstlane sits INSIDE the asm (with an "s" input this compiler hands the asm a VGPR
+// whenever it has the value in one) together with the wait states the hazard recogniser, which does not look inside an asm, would have
+// inserted: one between a VALU write of a VGPR and a v_readfirstlane of it (without it the values came out stale on gfx950), five
+// between a VALU write of an SGPR and a VMEM instruction that reads it.
+__device__ __forceinline__ int pin_dword(int v) { int o; asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(o) : "v"(v)); return o; }
+__device__ __forceinline__ int pin_s(int v) { return pin_dword(v); }
+__device__ __forceinline__ double pin_s(double v) { const int hi = pin_dword(__double2hiint(v)), lo = pin_dword(__double2loint(v)); return __hiloint2double(hi, lo); }
+struct TailK {
+    double r_move, r_too_close, r_in_box, r_in_dev, r_on_track, r_not_on_track, r_crash, low_reward;
+    int warm_start, max_steps, flags;
+};
+enum { TK_LOW_REWARD = 1, TK_AGGREGATE = 2 };
+__device__ __forceinline__ TailK tail_consts(const ftl_config& c) {
+    TailK K;
+    K.r_move = pin_s(c.leader_movement_reward); K.r_too_close = pin_s(c.too_close_penalty); K.r_in_box = pin_s(c.reward_in_box);
+    K.r_in_dev = pin_s(c.reward_in_dev); K.r_on_track = pin_s(c.reward_on_track); K.r_not_on_track = pin_s(c.not_on_track_penalty);
+    K.r_crash = pin_s(c.crash_penalty); K.low_reward = pin_s(c.low_reward);
+    K.warm_start = pin_s(c.warm_start); K.max_steps = pin_s(c.max_steps);
+    K.flags = pin_s((c.has_low_reward ? TK_LOW_REWARD : 0) | (c.aggregate_reward ? TK_AGGREGATE : 0));
+    return K;
+}
+
+// The tail of frame_step for one recorded frame (ENV:1077-1141): finish timer, early stopping, reward, step count, termination codes.
+// Nothing in a frame reads what it computes (the reference keeps simulating after `done`), so it runs over the records after the loop.
+__device__ __forceinline__ void g_tail(const TailK& K, GCtx& E, const int rec, int& sc, double& reward, int& i0, int& i1, int& i2) {
+    E.is_in_box = (rec & FR_IN_BOX) ? 1 : 0; E.is_on_trace = (rec & FR_ON_TRACE) ? 1 : 0; E.too_close = (rec & FR_TOO_CLOSE) ? 1 : 0;
+    i0 = FTL_MISSION_IN_PROGRESS; i1 = FTL_AGENT_MOVING; i2 = FTL_LEADER_MOVING;
+    if (rec & FR_LEADER_FINISHED) i2 = FTL_LEADER_FINISHED;          // ENV:1062-1065
+    if (rec & FR_COLLISION) { E.crash = 1; E.done = 1; i0 = FTL_MISSION_FAIL; i1 = FTL_AGENT_CRASH; }      // ENV:960-964
+    if (rec & FR_LEADER_HIT) { E.done = 1; i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_CRASH; }                 // ENV:1068-1072
+    if ((rec & FR_LEADER_FINISHED) && E.is_in_box) {       // ENV:1077-1087
         if (E.finish_timer < 0) E.finish_timer = 0;
         else {
             E.finish_timer += 1;
             if (E.finish_timer > E.fps * 20) { i0 = FTL_MISSION_SUCCESS; i2 = FTL_LEADER_FINISHED; i1 = FTL_AGENT_FINISHED; E.done = 1; }
         }
     }
-    if (E.step_count > c.warm_start) {                      // ENV:1088-1107
-        if (c.has_low_reward && E.acc_penalty < c.low_reward) { i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_LOW_REWARD; E.crash = 1; E.done = 1; }
-        if (c.has_max_distance_coef) {
-            float dx = fpx - lpx, dy = fpy - lpy;
-            float nrm = sqrtf(dx * dx + dy * dy);
-            if (nrm > (float)(c.max_distance * c.max_distance_coef)) { i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_TOO_FAR; E.crash = 1; E.done = 1; }
-        }
+    const bool warm = sc > K.warm_start;
+    if (warm) {                                             // ENV:1088-1107
+        if ((K.flags & TK_LOW_REWARD) && E.acc_penalty < K.low_reward) { i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_LOW_REWARD; E.crash = 1; E.done = 1; }
+        if (rec & FR_TOO_FAR) { i0 = FTL_MISSION_FAIL; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_TOO_FAR; E.crash = 1; E.done = 1; }
     }
     double res = 0;                                         // _reward_computation (ENV:1869-1904)
-    res += c.leader_movement_reward;
-    if (E.too_close) res += c.too_close_penalty;
+    res += K.r_move;
+    if (E.too_close) res += K.r_too_close;
     else {
-        if (E.is_in_box && E.is_on_trace) res += c.reward_in_box;
-        else if (E.is_in_box) res += c.reward_in_dev;
-        else if (E.is_on_trace) res += c.reward_on_track;
-        else if (E.step_count > c.warm_start) res += c.not_on_track_penalty;
+        if (E.is_in_box && E.is_on_trace) res += K.r_in_box;
+        else if (E.is_in_box) res += K.r_in_dev;
+        else if (E.is_on_trace) res += K.r_on_track;
+        else if (warm) res += K.r_not_on_track;
     }
-    if (E.crash) res += c.crash_penalty;
+    if (E.crash) res += K.r_crash;
     if (res < 0) E.acc_penalty += res; else E.acc_penalty = 0;
     E.overall_reward += res;
-    E.step_count += 1;
-    if (E.step_count > c.max_steps) { i0 = FTL_MISSION_FINISHED_BY_TIME; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_MOVING; E.done = 1; }
-    reward = c.aggregate_reward ? E.overall_reward : res;
-    FTL_TIC(3);
+    sc += 1;
+    if (sc > K.max_steps) { i0 = FTL_MISSION_FINISHED_BY_TIME; i2 = FTL_LEADER_MOVING; i1 = FTL_AGENT_MOVING; E.done = 1; }
+    reward = (K.flags & TK_AGGREGATE) ? E.overall_reward : res;
 }
 
 // ---- LeaderPositionsTracker_v2.scan (sensors.py:243-327), one env per group; the sequential parts (numpy pairwise
@@ -1282,9 +1360,8 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
             if (k < 0 || k > 4) E.error |= FTL_ERR_BAD_ACTION;    // reference: KeyError
         } else { a0 = 0.25; a1 = C.action[E.env]; }            // ENV:924-925
 
-        // this env's block bounding boxes stay in global memory: the searches that read them are rare now (an LDS copy per
-        // step measured 2 % slower than no copy once the caches of g_frame were in place, and cost 0.6 KB of traffic)
-        float4* bbl = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (P.cfg.traj_cap / FTL_TRAJ_BLOCK);
+        // (this env's block bounding boxes stay in global memory: the searches that read them are rare -- an LDS copy per
+        //  step measured 2 % slower than no copy once the search caches were in place, and cost 0.6 KB of traffic)
         g_build_near<G>(P, E, s_near, s_cnt);
         if (E.r == 1) {
             command_forward(E.rb, L, a0);                                   // ENV:927
@@ -1294,6 +1371,16 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         }
         double reward = 0; int i0 = 0, i1 = 0, i2 = 0;
         const int4* near = s_near + (size_t)E.slot * P.cfg.n_static;
+        // frame records, pending position checks (LDS offsets from the host, FtlDevParams::fr_*)
+        unsigned char* s_rec = lds + P.fr_rec_off;             // [slot][frame], rec_stride (a multiple of 16) bytes per env
+        const int rec_stride = P.fr_rec_stride;
+        FrPend* s_pend = reinterpret_cast<FrPend*>(lds + P.fr_pend_off);
+        int* s_env = reinterpret_cast<int*>(lds + P.fr_env_off);
+        int* s_pcnt = s_env + EPW;
+        if (E.r == 0) s_env[E.slot] = E.env;
+        if (threadIdx.x == 0) *s_pcnt = 0;
+        const bool defer = P.fr_defer != 0;              // the later frames' searches wait for the end of the step
+        int sc = E.step_count;                           // step_count as the tail sees it (the frames advance E.step_count themselves)
         __syncthreads();
         FTL_TIC(5);
         int tick = (E.step_count + 1) % P.cfg.trajectory_saving_period;
@@ -1305,8 +1392,42 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
 #endif
 #pragma nounroll
         for (int f = 0; f < f_max; f++) {
-            if (!REG || f < E.fps) g_frame<G, REG>(P, E, L, near, bbl, tick, reward, i0, i1, i2, f == 0);
+            bool pend = false; int pend_idx = -1; float new_ad = 3.0e38f;
+            if (!REG || f < E.fps) g_frame<G, REG>(P, E, L, near, tick, f == 0, f, s_rec, rec_stride, s_pend, s_pcnt, pend, pend_idx, new_ad);
             __syncthreads();          // an appended trajectory point is read by the other lanes of the group next frame
+            // The pending searches.  After the first frame (and after every frame when nothing is deferred) every env searches for
+            // itself: the next frames live on the caches these searches refresh.  After the last frame of a deferring step: everything
+            // the later frames left behind, sixteen items at a time, whichever envs they belong to.  (One call site: one copy of the code.)
+            if (f == 0 || !defer || f == f_max - 1) {
+                const int cnt = *s_pcnt;
+                if (cnt > 0) {        // wave-uniform
+                    const bool spread = defer && f > 0;
+                    int hint; float hx, hy, cg, ca;
+                    const int own = pend ? gb_i<G, 0>(pend_idx) : -1;
+                    g_resolve<G>(P, E, s_pend, s_rec, rec_stride, s_env, cnt, spread, own, hint, hx, hy, cg, ca);
+                    if (pend && !spread) {
+                        E.hint = hint;
+                        if (hx < 1.0e38f) { E.hx = hx; E.hy = hy; }
+                        if (cg >= 0.0f) E.clr_g = fminf(cg, new_ad);      // (the search did not see a point this frame appended)
+                        if (ca >= 0.0f) E.clr_a = fminf(ca, new_ad);
+                    }
+                    __syncthreads();
+                    if (threadIdx.x == 0) *s_pcnt = 0;
+                    __syncthreads();
+                }
+            }
+        }
+        FTL_TIC(11);
+        // the tail of every frame (ENV:1077-1141), from the records
+        const TailK TK = tail_consts(P.cfg);
+#pragma nounroll
+        for (int f0 = 0; f0 < f_max; f0 += 4) {        // four records per LDS read
+            const unsigned w = *reinterpret_cast<const unsigned*>(s_rec + E.slot * rec_stride + f0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int f = f0 + j;
+                if (f < f_max && (!REG || f < E.fps)) g_tail(TK, E, (int)((w >> (8 * j)) & 255u), sc, reward, i0, i1, i2);
+            }
         }
         if (REG && P.cfg.rand_fps_hi > 0) E.fps = d_rand_frames(P.cfg, E.env, E.resets, E.step_count);      // ENV:939-940: the next step's frames
         if (E.valid && E.r == 0) {
@@ -1370,7 +1491,13 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         // envs that hover around a threshold keep doing it
         int key;
         if (P.cfg.rand_fps_hi > 0) key = (fb << 3) | ((quiet && E.n_search <= 1 ? 0 : 1) << 2) | (3 - tc);
+#ifdef FTL_KEY_NOSEARCH
+        else key = (3 - tc);
+#elif defined(FTL_KEY_QUIETONLY)
+        else key = ((quiet ? 0 : 1) << 2) | (3 - tc);
+#else
         else key = (min(E.n_search, 7) << 3) | ((quiet ? 0 : 1) << 2) | (3 - tc);
+#endif
         if (E.r == 0) P.keys[E.env] = (uint8_t)key;
     }
     FTL_TIC(10);

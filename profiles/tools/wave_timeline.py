@@ -7,8 +7,9 @@ from golden_util import GOLDEN, config_for
 from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
 import bench
 W = os.environ.get("FTL_TIMELINE_WORKLOAD", "B")
-n = bench.DEFAULT_ENVS[W]
-cfg, pool, *_ = bench.build_workload(W, n, 0, 0, torch.device("cuda:0"))
+from continiousenvironment_follower_leader_amd import shard
+n = int(os.environ.get("FTL_DIAG_N", "0")) or shard.plan(W, 0, 1)[0].n
+cfg, pool, *_ = bench.build_workload(W, 0, 0, torch.device("cuda:0"))
 env = VecGame(n, device="cuda:0", config=cfg); env.load_scenarios(pool)
 env.reset((torch.arange(n) % pool.n).to(torch.int32))
 acts = bench.make_actions(cfg, n, 16, 0, torch.device("cuda:0"))

@@ -84,7 +84,7 @@ def _corner_grazes(env, cfg, bad):
 # session (tests/test_gpu_fuzz.py::test_zz_waiver_budget).  A graze shows up in up to max_prev_obs rows while its snapshot ages, so the
 # bound has a constant part of two such events.
 WAIVERS = dict(readings=0, corner=0, radar_env_steps=0, env_steps=0, radar_worst=0.0)
-CORNER_BUDGET = 1e-4
+CORNER_BUDGET = 1e-6
 
 
 def _compare_with_oracle(env, ora, cfg, tag):

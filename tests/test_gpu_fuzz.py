@@ -11,7 +11,7 @@ from continiousenvironment_follower_leader_amd import abi, make_config
 from oracle_batch import OracleBatch, pool_scenarios
 from test_gpu_configs import CORNER_BUDGET, WAIVERS, _actions, _compare_with_oracle, _vec
 
-RADAR_BUDGET = 0.05      # env-steps per config with a radar reading excused as a sector-boundary knife edge (tightened after measuring)
+RADAR_BUDGET = 0.01      # env-steps per config with a radar reading excused as a sector-boundary knife edge (worst of the 96 configs: 0.26 %; all of them together 6e-5)
 
 pytestmark = pytest.mark.gpu
 
