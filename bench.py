@@ -176,6 +176,10 @@ def main():
     ap.add_argument("--cpu-age", type=int, default=150, help="untimed ageing steps of the CPU baseline's population")
     ap.add_argument("--kernel-steps", type=int, default=100, help="steps of the per-kernel HIP-event pass after the timed region")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ring", type=int, default=0, metavar="HALF",
+                    help="draw the scenarios from a ScenarioRing of two halves of HALF entries that generator threads refill while the batch "
+                         "steps (fresh worlds, as the reference's reset() builds them) instead of the fixed pool; reports the window moves")
+    ap.add_argument("--gen-sample", type=int, default=4096, help="scenarios generated after the timed region to report the generator's rate (0: skip)")
     ap.add_argument("--workload", default="B", choices=["B", "D", "E", "F", "C", "L", "T"],
                     help="B: the configuration the metric is quoted on.  D, E: the other BASELINE configs.  F: the shipped training config.  "
                          "C, L, T (information only): config B's world with the row-f3 sensors -- compas ray sensors / lidars + leader-track "
@@ -211,15 +215,26 @@ def main():
     n = sh.n
     cfg, pool, workload_text, bpe, knames = build_workload(a.workload, sh.lo, a.seed, device)
     env = VecGame(n, device=device, config=cfg)
-    env.load_scenarios(pool)
-    # env e of this rank is GLOBAL env sh.lo + e and starts from scenario (seed*1000003 + sh.lo + e) mod P; auto-reset walks on by n_envs
-    env.reset(shard.scenario_index(a.seed, sh.lo, n, pool.n))
+    ring = None
+    if a.ring > 0:
+        from continiousenvironment_follower_leader_amd.scenario import ScenarioRing
+        import itertools
+        ring = ScenarioRing(cfg, a.ring, device, itertools.count(1000003 * (rank + 1)), n_threads=0)
+        ring.attach(env)
+        pool = ring.pool
+        env.reset(shard.scenario_index(a.seed, sh.lo, n, a.ring))
+    else:
+        env.load_scenarios(pool)
+        # env e of this rank is GLOBAL env sh.lo + e and starts from scenario (seed*1000003 + sh.lo + e) mod P; auto-reset walks on by n_envs
+        env.reset(shard.scenario_index(a.seed, sh.lo, n, pool.n))
     n_sets = 16
     acts = make_actions(cfg, n, n_sets, a.seed * 7919 + rank, device)
     torch.cuda.synchronize()
 
     k0 = 0
     for k in range(a.age):                     # ageing: untimed, uncounted
+        if ring is not None:
+            ring.poll(env, k)
         env.step(acts[(k0 + k) % n_sets], auto_reset=True)
     k0 += a.age
     torch.cuda.synchronize()
@@ -234,7 +249,10 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
+    swaps0 = ring.swaps if ring is not None else 0
     for k in range(a.steps):
+        if ring is not None:
+            ring.poll(env, k0 + k)
         env.step(acts[(k0 + k) % n_sets], auto_reset=True)
     ev1.record()
     torch.cuda.synchronize()
@@ -294,6 +312,17 @@ def main():
         if tenv is not env:
             tenv.close()
 
+    supply = None
+    if rank == 0 and a.gen_sample > 0:           # reset-time scenario generation (row f2): the host generator's rate on this box's cores
+        from continiousenvironment_follower_leader_amd.scenario import generate_scenarios
+        threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("FTL_CPU_THREADS", "16")))
+        tg = time.perf_counter()
+        gsc = generate_scenarios(cfg, np.arange(5000000, 5000000 + a.gen_sample), threads)
+        tg = time.perf_counter() - tg
+        supply = {"generator_scenarios_per_s": a.gen_sample / tg, "threads": threads, "usable_fraction": float(gsc["usable"].mean())}
+    if ring is not None:
+        supply = dict(supply or {}, ring_half=a.ring, window_moves_in_timed_region=ring.swaps - swaps0, scenarios_generated=ring.generated)
+        ring.close()
     if rank == 0:
         m = metrics.tolist()
         if ktimes:
@@ -329,6 +358,8 @@ def main():
                        "age_steps": a.age,
                        "episode_metrics": dict(zip(shard.METRIC_NAMES, m)),
                        "mean_return": m[1] / m[0] if m[0] else None, "mean_episode_frames": m[2] / m[0] if m[0] else None,
+                       "resets_per_s": m[0] / (dt * (a.steps + a.warmup) / a.steps) if dt > 0 else None,     # episodes that ended (= auto-resets) per second
+                       "scenario_supply": supply,
                        "envs_with_error_flags": n_err, "error_bits": err_bits},
             "roofline": roof,
         }

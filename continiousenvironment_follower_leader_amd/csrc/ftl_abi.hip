@@ -45,6 +45,7 @@ struct ftl_handle {
     // optionally the slot groups are stepped as two interleaved halves on two streams (the caller's stream waits for the side
     // stream): the ray kernel of one half fills the tail of the other half's frame kernel
     hipStream_t side; hipEvent_t ev_fork, ev_join; bool split;
+    int win_base, win_count; // pool entries the auto-reset draws from (ftl_set_reset_window)
     size_t lds_pad;          // FTL_DEBUG_LDS_PAD (diagnostic: lowers the frame kernel's occupancy without touching the code), read once at create
 };
 
@@ -322,6 +323,15 @@ int ftl_load_scenarios(ftl_handle* h, const ftl_scenarios* pool) {
         return fail(FTL_E_INVALID, "scenario pool has null arrays");
     h->P.scen = *pool;
     h->have_scen = true; h->dirty = true;
+    h->win_base = 0; h->win_count = pool->n_scenarios;
+    return FTL_OK;
+}
+
+int ftl_set_reset_window(ftl_handle* h, int32_t base, int32_t count) {
+    if (!h) return fail(FTL_E_INVALID, "null argument");
+    if (!h->have_scen) return fail(FTL_E_STATE, "ftl_load_scenarios has not been called");
+    if (base < 0 || count <= 0 || base + count > h->P.scen.n_scenarios) return fail(FTL_E_INVALID, "reset window outside the scenario pool");
+    h->win_base = base; h->win_count = count;
     return FTL_OK;
 }
 
@@ -461,7 +471,7 @@ int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const
     int rc = check_out(h, out);
     if (rc) return rc;
     if (out->policy_obs && h->P.pol_h <= 0) return fail(FTL_E_INVALID, "policy_obs needs the same max_prev_obs on every ray sensor");
-    FtlCall call; call.mode = 1; call.scen_idx = scen_idx; call.mask = mask; call.out = *out; call.action = nullptr; call.flags = 0; call.action_kind = FTL_ACTION_BOX2;
+    FtlCall call; call.mode = 1; call.scen_idx = scen_idx; call.mask = mask; call.out = *out; call.action = nullptr; call.flags = 0; call.action_kind = FTL_ACTION_BOX2; call.win_base = h->win_base; call.win_count = h->win_count;
     return launch(h, call, stream);
 }
 
@@ -477,7 +487,7 @@ int ftl_step_encoded(ftl_handle* h, const void* action, int32_t encoding, const 
     int rc = check_out(h, out);
     if (rc) return rc;
     if (out->policy_obs && h->P.pol_h <= 0) return fail(FTL_E_INVALID, "policy_obs needs the same max_prev_obs on every ray sensor");
-    FtlCall call; call.mode = 0; call.action = (const double*)action; call.action_kind = encoding; call.out = *out; call.flags = flags; call.scen_idx = nullptr; call.mask = nullptr;
+    FtlCall call; call.mode = 0; call.action = (const double*)action; call.action_kind = encoding; call.out = *out; call.flags = flags; call.scen_idx = nullptr; call.mask = nullptr; call.win_base = h->win_base; call.win_count = h->win_count;
     return launch(h, call, stream);
 }
 

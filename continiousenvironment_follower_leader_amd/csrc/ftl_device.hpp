@@ -78,6 +78,7 @@ struct FtlCall {
     ftl_outputs out;
     uint32_t flags; int32_t mode;      // mode 0 = step, 1 = reset
     int32_t action_kind;               // FTL_ACTION_*: how `action` is encoded (ftl_step_encoded)
+    int32_t win_base, win_count;       // pool entries the auto-reset draws from (ftl_set_reset_window)
     int32_t part, parts, epw;          // this launch covers the slot groups (epw consecutive slots = one frame-kernel wavefront)
                                        // part, part + parts, part + 2*parts, ... of the slot -> env permutation
 };

@@ -1456,7 +1456,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
             wt_reset = true;
 #endif
             if (go) { E.episodes += 1; E.err_acc |= E.error; }
-            g_reset<G>(P, E, go ? (E.scen + P.n_envs) % P.scen.n_scenarios : E.scen, go);
+            g_reset<G>(P, E, go ? C.win_base + ((E.scen % C.win_count) + P.n_envs) % C.win_count : E.scen, go);
             __syncthreads();
         }
     }

@@ -73,3 +73,115 @@ def generate_scenarios(cfg: GameConfig, seeds, n_threads=0):
     out["status"] = status
     out["usable"] = ((status & abi.SCEN_FOUND) != 0) & ((status & USABLE_MASK) == 0)
     return out
+
+
+class ScenarioRing:
+    """Fresh worlds for a running batch: a device pool of two halves; the envs' auto-reset draws from one half while generator threads
+    build the next scenarios on the host (``ftl_generate_scenarios``) and an asynchronous copy fills the other half; ``poll`` moves the
+    reset window (``ftl_set_reset_window``) at a step boundary.  The reference draws a new world on EVERY reset() (ENV:461-492); here a
+    world is drawn for every pool entry of every half, i.e. one per ``resets per half / half size`` episodes -- the generator's rate
+    against the batch's reset rate decides that ratio (bench.py reports both).
+
+    A half is only overwritten after ``horizon`` steps have passed since the window left it: by then every episode that started on it
+    has ended (an episode lasts at most max_steps / frames_per_step + 1 steps), so no running env still reads its rects or route.
+
+    ``seeds`` = iterator of python seeds; unusable scenarios (route not found, ...) are skipped, so a half may take more than ``half``
+    seeds.  ``n_threads`` generator threads run inside one background python thread (the C call releases the GIL)."""
+
+    def __init__(self, cfg: GameConfig, half, device, seeds, n_threads=0, chunk=None, record=False):
+        import itertools
+        import threading
+        from .vec_game import ScenarioPool
+        self.cfg, self.half, self.device = cfg, int(half), device
+        self.pool = ScenarioPool.empty(cfg, 2 * self.half, device)
+        self._seeds = iter(seeds)
+        self._chunk = chunk or max(256, self.half // 4)
+        self._n_threads = n_threads
+        self._take = itertools.islice
+        c = cfg.c
+        fps = c.rand_fps_lo if c.rand_fps_hi > 0 else c.frames_per_step
+        self.horizon = c.max_steps // max(fps, 1) + 2
+        self._stream = torch.cuda.Stream(device=device)
+        self._ready = None            # host arrays of the next half (pinned), produced by the worker
+        self._lock = threading.Lock()
+        self._stop = False
+        self._pending = None          # (half index, cuda event) of a copy in flight
+        self.active = 0
+        self._left_at = {0: None, 1: -10 ** 9}   # step at which the window left each half (None: it is the active one)
+        self.generated = 0            # scenarios generated so far (usable ones)
+        self.swaps = 0
+        self.history = [] if record else None     # (step, half index, host arrays) of every half that went live (tests)
+        first = self._build_half()
+        if record:
+            self.history.append((0, 0, first))
+        self.pool.write(0, first, self._stream)
+        self._stream.synchronize()
+        self._worker = threading.Thread(target=self._work, daemon=True)
+        self._worker.start()
+
+    def _build_half(self):
+        keys = ("static_rects", "robot_pos", "robot_dir", "robot_rect", "route", "route_len", "init_traj", "init_traj_len")
+        parts, have = [], 0
+        while have < self.half:
+            seeds = list(self._take(self._seeds, self._chunk))
+            if not seeds:
+                raise StopIteration("the seed iterator of a ScenarioRing ran dry")
+            g = generate_scenarios(self.cfg, seeds, self._n_threads)
+            keep = np.nonzero(g["usable"])[0][:self.half - have]
+            parts.append({k: g[k][keep] for k in keys})
+            have += len(keep)
+        host = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([p[k] for p in parts]))).pin_memory() for k in keys}
+        self.generated += self.half
+        return host
+
+    def _work(self):
+        import time
+        while not self._stop:
+            with self._lock:
+                need = self._ready is None
+            if need:
+                try:
+                    host = self._build_half()
+                except StopIteration:
+                    return
+                with self._lock:
+                    self._ready = host
+            else:
+                time.sleep(0.001)
+
+    def attach(self, env):
+        """Load the ring's pool into ``env`` with the reset window on the first half."""
+        env.load_scenarios(self.pool)
+        env.set_reset_window(0, self.half)
+
+    def poll(self, env, step):
+        """Call between steps with the number of steps taken so far.  Starts the copy of a finished half into the inactive half once
+        that half is free, and moves the reset window once the copy has landed.  Returns True when the window moved."""
+        other = 1 - self.active
+        if self._pending is not None:
+            h, ev = self._pending
+            if ev.query():
+                self._pending = None
+                self._left_at[self.active] = step
+                self.active = h
+                self._left_at[h] = None
+                env.set_reset_window(h * self.half, self.half)
+                self.swaps += 1
+                if self.history is not None:
+                    self.history.append((step, h, self._held))
+                return True
+            return False
+        left = self._left_at[other]
+        if left is not None and step - left >= self.horizon:
+            with self._lock:
+                host, self._ready = self._ready, None
+            if host is not None:
+                self._held = host        # keep the pinned buffers alive until the copy has landed
+                self.pool.write(other * self.half, host, self._stream)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+                self._pending = (other, ev)
+        return False
+
+    def close(self):
+        self._stop = True

@@ -5,6 +5,7 @@ follow_the_leader_continuous_env.py:434-543, 908-945).
 PyTorch is used for plumbing only: it owns the device buffers (state blob, scenario pool, outputs) and the
 stream; all arithmetic happens in ``libftl_hip.so`` behind the C-ABI of ``include/ftl.h``."""
 import ctypes as C
+from contextlib import nullcontext as _nullcontext
 
 import numpy as np
 import torch
@@ -18,7 +19,9 @@ _DT = {0: torch.int32, 1: torch.float32, 2: torch.float64}
 class ScenarioPool:
     """Post-reset scenarios (the output of the reference's reset-time generation, ENV:434-539) as device arrays."""
 
-    def __init__(self, cfg: GameConfig, static_rects, robot_pos, robot_dir, robot_rect, routes, init_trajs, device):
+    @staticmethod
+    def pack(cfg: GameConfig, static_rects, robot_pos, robot_dir, robot_rect, routes, init_trajs):
+        """Host arrays in the layout of ``ftl_scenarios`` (routes / initial trajectories padded to route_cap / init_traj_cap)."""
         c = cfg.c
         P = len(robot_pos)
         R = cfg.n_robots
@@ -43,20 +46,48 @@ class ScenarioPool:
             route_len[i] = len(r)
             it[i, :len(t)] = t
             it_len[i] = len(t)
+        return dict(static_rects=np.ascontiguousarray(sr),
+                    robot_pos=np.ascontiguousarray(np.asarray(robot_pos, np.float32).reshape(P, R, 2)),
+                    robot_dir=np.ascontiguousarray(np.asarray(robot_dir, np.float64).reshape(P, R)),
+                    robot_rect=np.ascontiguousarray(np.asarray(robot_rect, np.int32).reshape(P, R, 4)),
+                    route=route, route_len=route_len, init_traj=it, init_traj_len=it_len)
+
+    def __init__(self, cfg: GameConfig, static_rects, robot_pos, robot_dir, robot_rect, routes, init_trajs, device):
+        host = self.pack(cfg, static_rects, robot_pos, robot_dir, robot_rect, routes, init_trajs)
         dev = torch.device(device)
-        self.n = P
-        self.t = dict(
-            static_rects=torch.from_numpy(np.ascontiguousarray(sr)).to(dev),
-            robot_pos=torch.from_numpy(np.ascontiguousarray(np.asarray(robot_pos, np.float32).reshape(P, R, 2))).to(dev),
-            robot_dir=torch.from_numpy(np.ascontiguousarray(np.asarray(robot_dir, np.float64).reshape(P, R))).to(dev),
-            robot_rect=torch.from_numpy(np.ascontiguousarray(np.asarray(robot_rect, np.int32).reshape(P, R, 4))).to(dev),
-            route=torch.from_numpy(route).to(dev), route_len=torch.from_numpy(route_len).to(dev),
-            init_traj=torch.from_numpy(it).to(dev), init_traj_len=torch.from_numpy(it_len).to(dev))
+        self.n = len(host["robot_pos"])
+        self.t = {k: torch.from_numpy(v).to(dev) for k, v in host.items()}
+        self._bind()
+
+    def _bind(self):
         s = abi.Scenarios()
-        s.n_scenarios = P
+        s.n_scenarios = self.n
         for k, v in self.t.items():
             setattr(s, k, v.data_ptr())
         self.c_struct = s
+
+    @classmethod
+    def empty(cls, cfg: GameConfig, capacity, device):
+        """A pool of ``capacity`` zeroed entries to be filled with ``write`` (ScenarioRing)."""
+        c, R = cfg.c, cfg.n_robots
+        shapes = dict(static_rects=((capacity, c.n_static, 4), torch.int32), robot_pos=((capacity, R, 2), torch.float32),
+                      robot_dir=((capacity, R), torch.float64), robot_rect=((capacity, R, 4), torch.int32),
+                      route=((capacity, c.route_cap, 2), torch.float64), route_len=((capacity,), torch.int32),
+                      init_traj=((capacity, c.init_traj_cap, 2), torch.float32), init_traj_len=((capacity,), torch.int32))
+        self = cls.__new__(cls)
+        self.n = int(capacity)
+        self.t = {k: torch.zeros(sh, dtype=dt, device=device) for k, (sh, dt) in shapes.items()}
+        self._bind()
+        return self
+
+    def write(self, base, host, stream=None):
+        """Copy host arrays (``pack`` layout, pinned for an asynchronous copy) over entries ``[base, base + n)`` on ``stream``."""
+        n = len(host["robot_pos"])
+        if base < 0 or base + n > self.n:
+            raise ValueError("entries outside the pool")
+        with torch.cuda.stream(stream) if stream is not None else _nullcontext():
+            for k, v in host.items():
+                self.t[k][base:base + n].copy_(v if isinstance(v, torch.Tensor) else torch.from_numpy(v), non_blocking=True)
 
     @classmethod
     def generate(cls, cfg, seeds, device, n_threads=0):
@@ -67,10 +98,11 @@ class ScenarioPool:
         keep = np.nonzero(g["usable"])[0]
         if len(keep) == 0:
             raise ValueError("no usable scenario among the given seeds")
-        routes = [g["route"][i, :g["route_len"][i]] for i in keep]
-        trajs = [g["init_traj"][i, :g["init_traj_len"][i]] for i in keep]
-        pool = cls(cfg, g["static_rects"][keep], g["robot_pos"][keep], g["robot_dir"][keep], g["robot_rect"][keep],
-                   routes, trajs, device)
+        pool = cls.__new__(cls)
+        pool.n = len(keep)
+        pool.t = {k: torch.from_numpy(np.ascontiguousarray(g[k][keep])).to(device) for k in
+                  ("static_rects", "robot_pos", "robot_dir", "robot_rect", "route", "route_len", "init_traj", "init_traj_len")}
+        pool._bind()
         pool.seeds = g["seed"][keep]
         return pool
 
@@ -170,6 +202,11 @@ class VecGame:
     def load_scenarios(self, pool: ScenarioPool):
         self.pool = pool
         _lib.check(self.lib.ftl_load_scenarios(self.h, C.byref(pool.c_struct)), self.lib)
+
+    def set_reset_window(self, base, count):
+        """Pool entries ``[base, base + count)`` the in-kernel auto-reset draws from (``ftl_set_reset_window``; the whole pool after
+        ``load_scenarios``): how a ``ScenarioRing`` hands freshly generated worlds to a running batch."""
+        _lib.check(self.lib.ftl_set_reset_window(self.h, int(base), int(count)), self.lib)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

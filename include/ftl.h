@@ -305,6 +305,14 @@ int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_
 /* reset() part 1 (ENV:461-492): hand over the scenario pool produced by reset-time generation. */
 int ftl_load_scenarios(ftl_handle* h, const ftl_scenarios* pool);
 
+/* The pool entries the in-kernel auto-reset (FTL_STEP_AUTO_RESET) draws from: a finished env that ran scenario s restarts from
+ * base + ((s mod count) + n_envs) mod count.  ftl_load_scenarios sets the window to the whole pool (base 0, count n_scenarios), which is
+ * the walk documented at FTL_STEP_AUTO_RESET.  A caller that refills one half of a double-sized pool while the envs draw from the other
+ * half (the reference builds a fresh world on every reset(), ENV:461-492; scenario.ScenarioRing) moves the window between steps; entries
+ * outside the window stay valid for the episodes that are still running on them, so a half may be overwritten once every episode that
+ * started before the window left it has ended (at most max_steps / frames_per_step + 1 steps). */
+int ftl_set_reset_window(ftl_handle* h, int32_t base, int32_t count);
+
 /* reset() (ENV:494-543): place env e at scenario scen_idx[e] for every e with mask[e] != 0 (mask NULL = all),
  * run the initial use_sensors (ENV:541) and write the first observation.  reward/done/status are zeroed. */
 int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const ftl_outputs* out, void* stream);

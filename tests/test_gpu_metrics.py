@@ -153,3 +153,29 @@ def test_game_facade_raises_what_the_reference_raises():
     with pytest.raises((UnboundLocalError, IndexError)):
         g.reset()
     g.close()
+
+
+def test_stop_and_go_soak_keeps_every_capacity():
+    """Whole episodes (max_steps 5000 frames = 500 steps, with auto-reset into second episodes) under a stop-and-go follower on configs B
+    and D: the tracker ring is sized from the leader's point spacing with 2.5x head-room (config.py), the trajectory slot from max_steps --
+    neither may overflow (FTL_ERR_CORR_OVERFLOW / FTL_ERR_TRAJ_OVERFLOW would make the results diverge from the reference silently)."""
+    from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
+    from golden_util import load_episode
+    for ep, n in (("B_s1_chase", 2048), ("D_s2_chase", 512)):
+        _, meta = load_episode(ep)
+        cfg = config_for(meta, scen_route_len=256)
+        env = VecGame(n, device="cuda:0", config=cfg)
+        env.load_scenarios(ScenarioPool.generate(cfg, np.arange(300), "cuda:0"))
+        env.reset()
+        ms, mr = cfg.c.follower.max_speed, cfg.c.follower.max_rotation_speed
+        gen = torch.Generator(device="cpu"); gen.manual_seed(3)
+        phase = torch.arange(n) % 7
+        for t in range(560):
+            v = (0.6 + 0.4 * torch.rand(n, generator=gen, dtype=torch.float64)) * ms
+            v[((t // 12) + phase) % 3 == 0] = 0.0                      # a third of the envs stand still for 12 steps at a time
+            w = torch.clamp(torch.randn(n, generator=gen, dtype=torch.float64) * 0.15 * mr, -mr, mr)
+            env.step(torch.stack([v, w], 1).to("cuda:0"), auto_reset=True)
+        assert env.error_report() == (0, 0), (ep, env.error_report())
+        m = env.episode_metrics().tolist()
+        assert m[0] >= n                                               # every slot finished at least one episode on average
+        env.close()

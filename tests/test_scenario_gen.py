@@ -137,3 +137,61 @@ def test_generated_pool_runs_on_device():
     assert (ei[:, abi.EI_ERROR] == 0).all()
     assert np.isfinite(env.obs_num.cpu().numpy()).all() and np.isfinite(env.lasers.cpu().numpy()).all()
     env.close()
+
+
+@pytest.mark.gpu
+def test_scenario_ring_refills_while_stepping():
+    """ScenarioRing (row f2 at the step rate): generator threads build the next half of the pool while the batch steps, an asynchronous copy
+    fills the half no running episode can still read, the reset window moves at a step boundary.  A second run that writes the SAME halves
+    synchronously at the SAME steps must produce identical outputs at every step: the background generation, the side-stream copy and the
+    event-gated window move neither race with the kernels nor overwrite a scenario in use."""
+    import time
+    import torch
+    from continiousenvironment_follower_leader_amd.scenario import ScenarioRing
+    from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
+    z = np.load(GOLDEN + "/pool_B.npz")
+    meta = json.loads(str(z["meta"]))
+    cfg = config_for(dict(kwargs=dict(meta["kwargs"], max_steps=120, warm_start=10), post=None), scen_route_len=256)
+    n, half, T = 512, 96, 90
+    ms, mr = cfg.c.follower.max_speed, cfg.c.follower.max_rotation_speed
+    gen = torch.Generator(device="cpu"); gen.manual_seed(7)
+    acts = [torch.stack([(0.5 + 0.5 * torch.rand(n, generator=gen, dtype=torch.float64)) * ms,
+                         torch.clamp(torch.randn(n, generator=gen, dtype=torch.float64) * 0.2 * mr, -mr, mr)], 1).to("cuda:0") for _ in range(T)]
+
+    ring = ScenarioRing(cfg, half, "cuda:0", iter(range(20000, 10 ** 9)), n_threads=4, record=True)
+    assert ring.horizon == 120 // 10 + 2
+    a = VecGame(n, device="cuda:0", config=cfg)
+    ring.attach(a)
+    idx = (torch.arange(n) % half).to(torch.int32)
+    a.reset(idx)
+    outs = []
+    for t in range(T):
+        ring.poll(a, t)
+        a.step(acts[t], auto_reset=True)
+        outs.append((a.obs_num.clone(), a.lasers.clone(), a.reward.clone(), a.done.clone(), a.status.clone()))
+        if t % 10 == 9:
+            torch.cuda.synchronize(); time.sleep(0.05)      # give the generator threads time: several window moves inside the run
+    ring.close()
+    assert ring.swaps >= 3, ring.swaps                      # halves 1, 0, 1, ... went live while the batch was stepping
+    scen = a.state_field("env_int")[:, abi.EI_SCEN].cpu().numpy()
+    assert scen.min() >= 0 and scen.max() < 2 * half
+    assert a.error_report() == (0, 0)
+
+    b = VecGame(n, device="cuda:0", config=cfg)              # the same halves, written synchronously at the same steps
+    pool = ScenarioPool.empty(cfg, 2 * half, "cuda:0")
+    hist = list(ring.history)
+    pool.write(0, hist[0][2]); torch.cuda.synchronize()
+    b.load_scenarios(pool); b.set_reset_window(0, half)
+    b.reset(idx)
+    # a half is copied some steps BEFORE it goes live; writing it at the step it goes live is only equivalent because no episode reads it in between
+    for t in range(T):
+        for (st, h, host) in hist[1:]:
+            if st == t:
+                pool.write(h * half, host); torch.cuda.synchronize()
+                b.set_reset_window(h * half, half)
+        b.step(acts[t], auto_reset=True)
+        for x, y in zip(outs[t], (b.obs_num, b.lasers, b.reward, b.done, b.status)):
+            assert torch.equal(x, y), t
+    assert torch.equal(a.state_field("env_int")[:, abi.EI_SCEN], b.state_field("env_int")[:, abi.EI_SCEN])
+    assert int(a.state_field("env_int")[:, abi.EI_EPISODES].sum()) > n        # every env went through several worlds
+    a.close(); b.close()
