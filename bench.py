@@ -219,7 +219,9 @@ def main():
     if a.ring > 0:
         from continiousenvironment_follower_leader_amd.scenario import ScenarioRing
         import itertools
-        ring = ScenarioRing(cfg, a.ring, device, itertools.count(1000003 * (rank + 1)), n_threads=0)
+        # (two cores stay with the thread that launches the kernels: at ~3,000 steps/s it is the other thing this process does)
+        gthreads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("FTL_CPU_THREADS", "16"))) - 2)
+        ring = ScenarioRing(cfg, a.ring, device, itertools.count(1000003 * (rank + 1)), n_threads=gthreads)
         ring.attach(env)
         pool = ring.pool
         env.reset(shard.scenario_index(a.seed, sh.lo, n, a.ring))

@@ -63,9 +63,9 @@ def load():
     lib.ftl_state_bytes.argtypes = [vp]
     lib.ftl_state_bytes.restype = C.c_size_t
     lib.ftl_bind_state.argtypes = [vp, vp, C.c_size_t]
-    lib.ftl_state_field.argtypes = [vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(i32)]
+    lib.ftl_state_field.argtypes = [vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(i32), C.POINTER(C.c_size_t)]
     lib.ftl_load_scenarios.argtypes = [vp, C.POINTER(abi.Scenarios)]
-    lib.ftl_set_reset_window.argtypes = [vp, i32, i32]
+    lib.ftl_set_reset_window.argtypes = [vp, i32, i32, i32]
     lib.ftl_reset.argtypes = [vp, vp, vp, C.POINTER(abi.Outputs), vp]
     lib.ftl_step.argtypes = [vp, vp, C.POINTER(abi.Outputs), u32, vp]
     lib.ftl_step_encoded.argtypes = [vp, vp, i32, C.POINTER(abi.Outputs), u32, vp]

@@ -4,7 +4,7 @@ Field order and types must match the header exactly; ``tests/test_abi.py`` check
 against ``ftl_sizeof_*`` exported by the library."""
 import ctypes as C
 
-FTL_ABI_VERSION = 3
+FTL_ABI_VERSION = 4
 FTL_MAX_BEARS = 6
 FTL_MAX_LASERS = 4
 FTL_MAX_AUX = 8

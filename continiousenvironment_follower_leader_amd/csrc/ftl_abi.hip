@@ -21,7 +21,7 @@ thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
-struct Field { const char* name; size_t offset, per_env; int dtype; };
+struct Field { const char* name; size_t offset, per_env; int dtype; size_t stride; };     // stride: bytes from one env's row to the next
 constexpr int FTL_N_FIELDS = 14;
 
 }  // namespace
@@ -45,7 +45,7 @@ struct ftl_handle {
     // optionally the slot groups are stepped as two interleaved halves on two streams (the caller's stream waits for the side
     // stream): the ray kernel of one half fills the tail of the other half's frame kernel
     hipStream_t side; hipEvent_t ev_fork, ev_join; bool split;
-    int win_base, win_count; // pool entries the auto-reset draws from (ftl_set_reset_window)
+    int win_base, win_count, win_stride; // pool entries the auto-reset draws from (ftl_set_reset_window)
     size_t lds_pad;          // FTL_DEBUG_LDS_PAD (diagnostic: lowers the frame kernel's occupancy without touching the code), read once at create
 };
 
@@ -210,19 +210,32 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         }
         P.pol_width = w; P.pol_h = hcommon;
     }
-    // state layout: one region per field, [n_envs][per_env], 256-byte aligned
+    // State layout.  The small fields of an env form one record (fields in the order below, the ray kernel's inputs first; 16-byte aligned
+    // fields, a stride that is a multiple of 128 bytes); the long ones are [n_envs][per_env] arrays in 256-byte aligned regions.
     const size_t n = (size_t)n_envs;
-    struct { const char* name; size_t per_env; int dtype; size_t esz; } spec[FTL_N_FIELDS] = {
-        {"rb_pos", (size_t)P.R * 2, 1, 4}, {"rb_dbl", (size_t)P.R * FTL_RD_COUNT, 2, 8}, {"rb_int", (size_t)P.R * FTL_RI_COUNT, 0, 4},
-        {"env_int", FTL_EI_COUNT, 0, 4}, {"env_dbl", FTL_ED_COUNT, 2, 8}, {"traj", (size_t)cfg->traj_cap * 2, 1, 4},
-        {"hist", (size_t)cfg->corr_cap * 2, 2, 8}, {"corr", (size_t)cfg->corr_cap * 4, 2, 8},
-        {"snap_rects", (size_t)hmax * (P.R - 1) * 4, 0, 4}, {"snap_win", (size_t)hmax * 4, 0, 4},
-        {"traj_bb", (size_t)(cfg->traj_cap / FTL_TRAJ_BLOCK) * 4, 1, 4}, {"ep_stats", FTL_N_METRICS, 2, 8},
-        {"hist1", (size_t)(cfg->has_tracker == 1 ? cfg->hist1_cap : 0) * 2, 1, 4}, {"fol_cs", 2, 2, 8}};
-    size_t cur = 0;
+    struct { const char* name; size_t per_env; int dtype; size_t esz; bool rec; } spec[FTL_N_FIELDS] = {
+        {"rb_pos", (size_t)P.R * 2, 1, 4, true}, {"rb_dbl", (size_t)P.R * FTL_RD_COUNT, 2, 8, true}, {"rb_int", (size_t)P.R * FTL_RI_COUNT, 0, 4, true},
+        {"env_int", FTL_EI_COUNT, 0, 4, true}, {"env_dbl", FTL_ED_COUNT, 2, 8, true}, {"traj", (size_t)cfg->traj_cap * 2, 1, 4, false},
+        {"hist", (size_t)cfg->corr_cap * 2, 2, 8, false}, {"corr", (size_t)cfg->corr_cap * 4, 2, 8, false},
+        {"snap_rects", (size_t)hmax * (P.R - 1) * 4, 0, 4, true}, {"snap_win", (size_t)hmax * 4, 0, 4, true},
+        {"traj_bb", (size_t)(cfg->traj_cap / FTL_TRAJ_BLOCK) * 4, 1, 4, false}, {"ep_stats", FTL_N_METRICS, 2, 8, false},
+        {"hist1", (size_t)(cfg->has_tracker == 1 ? cfg->hist1_cap : 0) * 2, 1, 4, false}, {"fol_cs", 2, 2, 8, true}};
+    static const int rec_order[8] = {3 /*env_int*/, 13 /*fol_cs*/, 0 /*rb_pos*/, 1 /*rb_dbl*/, 9 /*snap_win*/, 8 /*snap_rects*/, 4 /*env_dbl*/, 2 /*rb_int*/};
+    size_t ro = 0;
+    for (int k = 0; k < 8; k++) {
+        const int i = rec_order[k];
+        ro = align_up(ro, 16);
+        h->fields[i] = Field{spec[i].name, ro, spec[i].per_env, spec[i].dtype, 0};
+        ro += spec[i].per_env * spec[i].esz;
+    }
+    const size_t rec_stride = align_up(ro, 128);
+    P.rec_stride = (int32_t)rec_stride;
+    for (int k = 0; k < 8; k++) h->fields[rec_order[k]].stride = rec_stride;
+    size_t cur = rec_stride * n;
     for (int i = 0; i < FTL_N_FIELDS; i++) {
+        if (spec[i].rec) continue;
         cur = align_up(cur, 256);
-        h->fields[i] = Field{spec[i].name, cur, spec[i].per_env, spec[i].dtype};
+        h->fields[i] = Field{spec[i].name, cur, spec[i].per_env, spec[i].dtype, spec[i].per_env * spec[i].esz};
         cur += spec[i].per_env * spec[i].esz * n;
     }
     h->state_bytes = align_up(cur, 256);
@@ -287,13 +300,14 @@ int ftl_get_config(const ftl_handle* h, ftl_config* out) {
 
 size_t ftl_state_bytes(const ftl_handle* h) { return h ? h->state_bytes : 0; }
 
-int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype) {
+int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype, size_t* stride) {
     if (!h || !name) return fail(FTL_E_INVALID, "null argument");
     for (int i = 0; i < FTL_N_FIELDS; i++)
         if (!strcmp(h->fields[i].name, name)) {
             if (offset) *offset = h->fields[i].offset;
             if (per_env) *per_env = h->fields[i].per_env;
             if (dtype) *dtype = h->fields[i].dtype;
+            if (stride) *stride = h->fields[i].stride;
             return FTL_OK;
         }
     return fail(FTL_E_INVALID, std::string("unknown state field ") + name);
@@ -323,15 +337,15 @@ int ftl_load_scenarios(ftl_handle* h, const ftl_scenarios* pool) {
         return fail(FTL_E_INVALID, "scenario pool has null arrays");
     h->P.scen = *pool;
     h->have_scen = true; h->dirty = true;
-    h->win_base = 0; h->win_count = pool->n_scenarios;
+    h->win_base = 0; h->win_count = pool->n_scenarios; h->win_stride = h->P.n_envs % pool->n_scenarios;
     return FTL_OK;
 }
 
-int ftl_set_reset_window(ftl_handle* h, int32_t base, int32_t count) {
+int ftl_set_reset_window(ftl_handle* h, int32_t base, int32_t count, int32_t stride) {
     if (!h) return fail(FTL_E_INVALID, "null argument");
     if (!h->have_scen) return fail(FTL_E_STATE, "ftl_load_scenarios has not been called");
     if (base < 0 || count <= 0 || base + count > h->P.scen.n_scenarios) return fail(FTL_E_INVALID, "reset window outside the scenario pool");
-    h->win_base = base; h->win_count = count;
+    h->win_base = base; h->win_count = count; h->win_stride = (stride > 0 ? stride : h->P.n_envs) % count;
     return FTL_OK;
 }
 
@@ -471,7 +485,7 @@ int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const
     int rc = check_out(h, out);
     if (rc) return rc;
     if (out->policy_obs && h->P.pol_h <= 0) return fail(FTL_E_INVALID, "policy_obs needs the same max_prev_obs on every ray sensor");
-    FtlCall call; call.mode = 1; call.scen_idx = scen_idx; call.mask = mask; call.out = *out; call.action = nullptr; call.flags = 0; call.action_kind = FTL_ACTION_BOX2; call.win_base = h->win_base; call.win_count = h->win_count;
+    FtlCall call; call.mode = 1; call.scen_idx = scen_idx; call.mask = mask; call.out = *out; call.action = nullptr; call.flags = 0; call.action_kind = FTL_ACTION_BOX2; call.win_base = h->win_base; call.win_count = h->win_count; call.win_stride = h->win_stride;
     return launch(h, call, stream);
 }
 
@@ -487,7 +501,7 @@ int ftl_step_encoded(ftl_handle* h, const void* action, int32_t encoding, const 
     int rc = check_out(h, out);
     if (rc) return rc;
     if (out->policy_obs && h->P.pol_h <= 0) return fail(FTL_E_INVALID, "policy_obs needs the same max_prev_obs on every ray sensor");
-    FtlCall call; call.mode = 0; call.action = (const double*)action; call.action_kind = encoding; call.out = *out; call.flags = flags; call.scen_idx = nullptr; call.mask = nullptr; call.win_base = h->win_base; call.win_count = h->win_count;
+    FtlCall call; call.mode = 0; call.action = (const double*)action; call.action_kind = encoding; call.out = *out; call.flags = flags; call.scen_idx = nullptr; call.mask = nullptr; call.win_base = h->win_base; call.win_count = h->win_count; call.win_stride = h->win_stride;
     return launch(h, call, stream);
 }
 

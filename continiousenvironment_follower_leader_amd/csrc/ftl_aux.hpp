@@ -21,10 +21,11 @@ __global__ void __launch_bounds__(256) ftl_tracker1_kernel(const FtlDevParams* _
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= P.n_envs) return;
     if (C.mode == 1 && C.mask && !C.mask[env]) return;
-    int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
+    int* ei = rec_field(P.env_int, P, env);
     int counter = ei[FTL_EI_TRK_COUNTER], hlen = ei[FTL_EI_HIST1_LEN], clen = ei[FTL_EI_CORR_HI], err = 0;
-    const float lpx = P.rb_pos[2 * ((size_t)env * P.R)], lpy = P.rb_pos[2 * ((size_t)env * P.R) + 1];
-    const float fpx = P.rb_pos[2 * ((size_t)env * P.R + 1)], fpy = P.rb_pos[2 * ((size_t)env * P.R + 1) + 1];
+    const float* rpos = rec_field(P.rb_pos, P, env);
+    const float lpx = rpos[0], lpy = rpos[1];
+    const float fpx = rpos[2], fpy = rpos[3];
     float2* h = reinterpret_cast<float2*>(P.hist1) + (size_t)env * c.hist1_cap;
     bool unchanged = false;
     if (counter % c.tracker_saving_period == 0) {
@@ -75,9 +76,9 @@ __global__ void __launch_bounds__(256) ftl_tracker1_kernel(const FtlDevParams* _
     if (groups) { if (clen > 1) ok = 1; else if (strict) err |= FTL_ERR_EMPTY_CORRIDOR; }
     if (ok) {
         const int slot = ei[FTL_EI_SNAP_HEAD];
-        int4* sr = reinterpret_cast<int4*>(P.snap_rects) + ((size_t)env * P.hmax + slot) * (P.R - 1);
-        for (int r = 0; r < P.R; r++) if (r != 1) sr[r == 0 ? 0 : r - 1] = reinterpret_cast<const int4*>(P.rb_int + ((size_t)env * P.R + r) * FTL_RI_COUNT)[0];
-        int* sw = P.snap_win + ((size_t)env * P.hmax + slot) * 4;
+        int4* sr = reinterpret_cast<int4*>(rec_field(P.snap_rects, P, env)) + slot * (P.R - 1);
+        for (int r = 0; r < P.R; r++) if (r != 1) sr[r == 0 ? 0 : r - 1] = reinterpret_cast<const int4*>(rec_field(P.rb_int, P, env) + r * FTL_RI_COUNT)[0];
+        int* sw = rec_field(P.snap_win, P, env) + slot * 4;
         sw[0] = 0; sw[1] = clen; sw[2] = 0; sw[3] = clen;
         ei[FTL_EI_SNAP_COUNT] += 1;
         ei[FTL_EI_SNAP_HEAD] = (slot + 1 == P.hmax) ? 0 : slot + 1;
@@ -119,11 +120,10 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const Ft
     const int env = blockIdx.x, lane = threadIdx.x;
     if (env >= P.n_envs) return;
     if (C.mode == 1 && C.mask && !C.mask[env]) return;
-    const int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
-    const size_t fo = (size_t)env * P.R + 1;
-    const float cxf = P.rb_pos[2 * fo], cyf = P.rb_pos[2 * fo + 1];
+    const int* ei = rec_field(P.env_int, P, env);
+    const float cxf = rec_field(P.rb_pos, P, env)[2], cyf = rec_field(P.rb_pos, P, env)[3];        // robot 1 = the follower
     const double cx = (double)cxf, cy = (double)cyf;
-    const double fdir = P.rb_dbl[fo * FTL_RD_COUNT + FTL_RD_DIRECTION];
+    const double fdir = rec_field(P.rb_dbl, P, env)[1 * FTL_RD_COUNT + FTL_RD_DIRECTION];
     float* out_base = C.out.lasers + (size_t)env * P.lasers_len;
     const unsigned long long kInf = 0x7fefffffffffffffull;
 
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const Ft
         double* s_c64 = reinterpret_cast<double*>(lds + (((size_t)P.hmax * 16 + 31) & ~(size_t)31));   // [FTL_COMPAS_STAGE][4] corridor points
         unsigned char* scratch = reinterpret_cast<unsigned char*>(s_c64 + 4 * FTL_COMPAS_STAGE);
         const int nvalid = snap_count < P.hmax ? snap_count : P.hmax;
-        if (lane < P.hmax * 4) s_winall[lane] = P.snap_win[(size_t)env * P.hmax * 4 + lane];
+        if (lane < P.hmax * 4) s_winall[lane] = rec_field(P.snap_win, P, env)[lane];
         __syncthreads();
         int passes = 0;                                   // scan passes (before / after the tracker's own dict entry) that have a compas sensor
         for (int k = 0; k < c.n_lasers; k++) if (c.lasers[k].compas) passes |= 1 << (c.lasers[k].after_tracker ? 1 : 0);
@@ -291,9 +291,9 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const Ft
             const int scen = ei[FTL_EI_SCEN];
             for (int o = lane; o < nobj; o += FTL_WAVE) {
                 int4 q;
-                if (o == 0) q = reinterpret_cast<const int4*>(P.rb_int + ((size_t)env * P.R) * FTL_RI_COUNT)[0];
+                if (o == 0) q = reinterpret_cast<const int4*>(rec_field(P.rb_int, P, env))[0];
                 else if (o <= c.n_static) q = reinterpret_cast<const int4*>(P.scen.static_rects)[(size_t)scen * c.n_static + (o - 1)];
-                else q = reinterpret_cast<const int4*>(P.rb_int + ((size_t)env * P.R + 2 + (o - 1 - c.n_static)) * FTL_RI_COUNT)[0];
+                else q = reinterpret_cast<const int4*>(rec_field(P.rb_int, P, env) + (2 + (o - 1 - c.n_static)) * FTL_RI_COUNT)[0];
                 const int px[8] = { q.x, q.x, q.x + q.z, q.x + q.z, q.x + (q.z >> 1), q.x, q.x + (q.z >> 1), q.x + q.z };
                 const int py[8] = { q.y, q.y + q.w, q.y, q.y + q.w, q.y, q.y + (q.w >> 1), q.y + q.w, q.y + (q.w >> 1) };
                 // min over the eight points of sqrt(d2) <= range  <=>  sqrt(min d2) <= range (sqrt and its rounding are monotone); away from
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const Ft
             }
             __syncthreads();
             if (lane == 0 && *s_cnt > FTL_LIDAR_RECTS) {
-                int* eiw = P.env_int + (size_t)env * FTL_EI_COUNT;
+                int* eiw = rec_field(P.env_int, P, env);
                 atomicOr(&eiw[FTL_EI_ERROR], (int)FTL_ERR_LIDAR_OVERFLOW); atomicOr(&eiw[FTL_EI_ERROR_STICKY], (int)FTL_ERR_LIDAR_OVERFLOW);
             }
             const int nin = min(*s_cnt, FTL_LIDAR_RECTS);

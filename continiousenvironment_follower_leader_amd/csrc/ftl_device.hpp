@@ -52,8 +52,13 @@ struct FtlDevParams {
                                       // (+ the item counter), "the later frames' position searches wait for the end of the step", total dynamic LDS
     int32_t corr_lds_cap;             // corridor points the ray kernel stages in LDS (a power of two <= cfg.corr_cap; a longer window is read in place)
     int32_t pol_off[FTL_MAX_LASERS], pol_width, pol_h;   // fused sensorPrev output: column offset per sensor (-1: not part of it), row width, common history
-    // per-env state (views into the caller-owned state buffer), all [n_envs][...]
+    // per-env state (views into the caller-owned state buffer).  The small fields every step reads and writes -- env_int, fol_cs, rb_pos,
+    // rb_dbl, snap_win, snap_rects, env_dbl, rb_int, in this order -- sit in ONE record of rec_stride bytes per env (a multiple of 128: the
+    // group that owns an env touches whole cache lines of its own, whatever the slot -> env permutation did to its neighbours; as six arrays
+    // they cost 1.6x the algorithmic HBM traffic in partial lines); these pointers address the field inside record 0: rec_field() below.
+    // The ray kernel's inputs come first, so it reads the head of the record only.  The long fields (traj .. hist1) are [n_envs][per_env] arrays.
     float* rb_pos; double* rb_dbl; int32_t* rb_int; int32_t* env_int; double* env_dbl;
+    int32_t rec_stride, _pad_rec;
     float* traj; double* hist; double* corr; int32_t* snap_rects; int32_t* snap_win;
     float* traj_bb;                   // [n_envs][traj_cap / FTL_TRAJ_BLOCK][4]: xmin, ymin, xmax, ymax of each block of trajectory points
     double* ep_stats;                 // [n_envs][FTL_N_METRICS]: metrics of the episodes that ended in this env slot (include/ftl.h)
@@ -78,10 +83,16 @@ struct FtlCall {
     ftl_outputs out;
     uint32_t flags; int32_t mode;      // mode 0 = step, 1 = reset
     int32_t action_kind;               // FTL_ACTION_*: how `action` is encoded (ftl_step_encoded)
-    int32_t win_base, win_count;       // pool entries the auto-reset draws from (ftl_set_reset_window)
+    int32_t win_base, win_count, win_stride;   // pool entries the auto-reset draws from and the step of its walk (ftl_set_reset_window)
     int32_t part, parts, epw;          // this launch covers the slot groups (epw consecutive slots = one frame-kernel wavefront)
                                        // part, part + parts, part + 2*parts, ... of the slot -> env permutation
 };
+
+// field `f0` (its address inside record 0) of env `env`
+template <typename T>
+__device__ __forceinline__ T* rec_field(T* f0, const FtlDevParams& P, size_t env) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(f0) + env * (size_t)P.rec_stride);
+}
 
 namespace ftl {
 
@@ -432,7 +443,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     unsigned short* s_edge = reinterpret_cast<unsigned short*>(s_cnt + 8);       // [4 * (cap_rs + cap_rd)]: rect slot << 2 | edge, the edges facing the follower
     const int n_u32 = (cap_rs + cap_rd) + cap_cr + cap_gr + 8 + 2 * (cap_rs + cap_rd);   // words since the last 16-byte aligned array
     double2* s_ray = reinterpret_cast<double2*>(s_rmask + ((n_u32 + 3) & ~3));     // 16-byte aligned [total_rays]
-    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [total_rays][HM]
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [HM][total_rays]
     double* s_miss = reinterpret_cast<double*>(s_best + (size_t)P.total_rays * HM);                     // [total_rays] |ray end - origin|
     unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_miss + P.total_rays);                  // [FTL_PAIR_CAP] candidate list of phase 3
     const unsigned long long kInfBits = 0x7fefffffffffffffull;                                       // DBL_MAX: "no hit"
@@ -440,17 +451,16 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     // Round trip 1: everything that is addressed by the env index alone is requested at once -- the scalars, every ring slot
     // of the snapshot windows (one word per lane) and of the snapshot rects (one rect per lane); which slots are valid is
     // sorted out after they have arrived.  Round trip 2 (below): corridor points and the scenario's static rects.
-    const int* ei = P.env_int + (size_t)env * FTL_EI_COUNT;
-    const int* swp = P.snap_win + (size_t)env * hmax * 4;
-    const int4* srp = reinterpret_cast<const int4*>(P.snap_rects) + (size_t)env * hmax * nrect_dyn;
+    const int* ei = rec_field(P.env_int, P, env);
+    const int* swp = rec_field(P.snap_win, P, env);
+    const int4* srp = reinterpret_cast<const int4*>(rec_field(P.snap_rects, P, env));
     const int swv = lane < hmax * 4 ? swp[lane] : 0;
     // per-env scalars come through VECTOR loads (one word per lane) and are made wave-uniform with readlane: streaming
     // them through the scalar cache (s_load) costs several microseconds per miss under this kernel's load
-    const size_t fo = (size_t)env * P.R + 1;            // follower
     const int eiv = lane < FTL_EI_COUNT ? ei[lane] : 0;
-    const int fpv = lane < 2 ? __float_as_int(P.rb_pos[2 * fo + lane]) : 0;
-    const int fdv = lane < 2 ? reinterpret_cast<const int*>(P.rb_dbl + fo * FTL_RD_COUNT + FTL_RD_DIRECTION)[lane] : 0;
-    const int fcv = lane < 4 ? reinterpret_cast<const int*>(P.fol_cs + 2 * (size_t)env)[lane] : 0;
+    const int fpv = lane < 2 ? __float_as_int(rec_field(P.rb_pos, P, env)[2 * 1 + lane]) : 0;                 // robot 1 = the follower
+    const int fdv = lane < 2 ? reinterpret_cast<const int*>(rec_field(P.rb_dbl, P, env) + 1 * FTL_RD_COUNT + FTL_RD_DIRECTION)[lane] : 0;
+    const int fcv = lane < 4 ? reinterpret_cast<const int*>(rec_field(P.fol_cs, P, env))[lane] : 0;
     const int scen = __builtin_amdgcn_readlane(eiv, FTL_EI_SCEN), snap_count = __builtin_amdgcn_readlane(eiv, FTL_EI_SNAP_COUNT);
     const int scan_ok = __builtin_amdgcn_readlane(eiv, FTL_EI_SCAN_OK), snap_head = __builtin_amdgcn_readlane(eiv, FTL_EI_SNAP_HEAD);
     const int newest = (snap_head == 0 ? hmax : snap_head) - 1;   // ring slot of the newest snapshot
@@ -613,7 +623,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 if (P.miss_const) s_miss[g] = (double)(float)len;                    // np.linalg.norm(end - position), sensors.py:925-930
                 else { const double qx0 = ex - (double)cx, qy0 = ey - (double)cy; s_miss[g] = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0)); }
 #pragma unroll
-                for (int j = 0; j < HM; j++) s_best[g * HM + j] = kInfBits;
+                for (int j = 0; j < HM; j++) s_best[j * P.total_rays + g] = kInfBits;       // [age][ray]: the lanes of a row read / write consecutive words
             }
         }
         __syncthreads();
@@ -667,7 +677,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sgx, d2)) {
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
 #pragma unroll
-                    for (int j = 0; j < HM; j++) if ((smx >> j) & 1u) atomicMin(&s_best[ray * HM + j], bits);
+                    for (int j = 0; j < HM; j++) if ((smx >> j) & 1u) atomicMin(&s_best[j * P.total_rays + ray], bits);
                 }
             };
             const float fdir_rad = (float)(fdir * kDeg2Rad);
@@ -833,7 +843,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                         const double lis = (double)N / 4.0, di = (double)i;         // lasers_in_sector (sensors.py:938)
                         col = (di < lis ? 0 : (di < 2 * lis ? 1 : (di < 3 * lis ? 2 : 3))) * N + i;
                     }
-                    const unsigned long long bb = s_best[(rb + i) * HM + a2];
+                    const unsigned long long bb = s_best[a2 * P.total_rays + rb + i];
                     const double v = (a2 < nsnap && bb != kInfBits) ? sqrt(__longlong_as_double((long long)bb)) : s_miss[rb + i];
                     const float vf = (float)v;
                     out_base[ooff + (H - 1 - a2) * Wd + col] = vf;

@@ -147,8 +147,8 @@ struct GCtx {
 
 template <int G>
 __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
-    const int* ei = P.env_int + (size_t)E.env * FTL_EI_COUNT;
-    const double* ed = P.env_dbl + (size_t)E.env * FTL_ED_COUNT;
+    const int* ei = rec_field(P.env_int, P, E.env);
+    const double* ed = rec_field(P.env_dbl, P, E.env);
     E.scen = ei[FTL_EI_SCEN]; E.cur_target_id = ei[FTL_EI_TARGET_ID]; E.leader_finished = ei[FTL_EI_LEADER_FINISHED];
     E.done = ei[FTL_EI_DONE]; E.crash = ei[FTL_EI_CRASH]; E.is_in_box = ei[FTL_EI_IN_BOX]; E.is_on_trace = ei[FTL_EI_ON_TRACE];
     E.too_close = ei[FTL_EI_TOO_CLOSE]; E.step_count = ei[FTL_EI_STEP_COUNT]; E.finish_timer = ei[FTL_EI_FINISH_TIMER];
@@ -164,12 +164,12 @@ __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
     E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
     E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1]; E.green_w = ed[FTL_ED_GREEN_W];
     int rr = (E.r < P.R) ? E.r : 0;          // idle lanes mirror robot 0 (never committed)
-    size_t ro = (size_t)E.env * P.R + rr;
-    E.rb.px = P.rb_pos[2 * ro]; E.rb.py = P.rb_pos[2 * ro + 1];
-    const double* rd = P.rb_dbl + ro * FTL_RD_COUNT;
+    const float* rp = rec_field(P.rb_pos, P, E.env) + 2 * rr;
+    E.rb.px = rp[0]; E.rb.py = rp[1];
+    const double* rd = rec_field(P.rb_dbl, P, E.env) + rr * FTL_RD_COUNT;
     E.rb.direction = rd[FTL_RD_DIRECTION]; E.rb.speed = rd[FTL_RD_SPEED]; E.rb.rot_speed = rd[FTL_RD_ROT_SPEED];
     E.rb.des_speed = rd[FTL_RD_DES_SPEED]; E.rb.des_rot_speed = rd[FTL_RD_DES_ROT_SPEED];
-    const int4* ri = reinterpret_cast<const int4*>(P.rb_int + ro * FTL_RI_COUNT);
+    const int4* ri = reinterpret_cast<const int4*>(rec_field(P.rb_int, P, E.env) + rr * FTL_RI_COUNT);
     int4 r0 = ri[0], r1 = ri[1];
     E.rb.rx = r0.x; E.rb.ry = r0.y; E.rb.rw = r0.z; E.rb.rh = r0.w; E.rb.rot_dir = r1.x; E.rb.des_rot_dir = r1.y;
     int b = (E.r >= 2 && E.r < P.R) ? E.r - 2 : 0;
@@ -181,8 +181,8 @@ __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
 template <int G>
 __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
     if (!E.valid) return;
-    int* ei = P.env_int + (size_t)E.env * FTL_EI_COUNT;
-    double* ed = P.env_dbl + (size_t)E.env * FTL_ED_COUNT;
+    int* ei = rec_field(P.env_int, P, E.env);
+    double* ed = rec_field(P.env_dbl, P, E.env);
     if (E.r == 0) {
         ei[FTL_EI_SCEN] = E.scen; ei[FTL_EI_TARGET_ID] = E.cur_target_id; ei[FTL_EI_LEADER_FINISHED] = E.leader_finished;
         ei[FTL_EI_DONE] = E.done; ei[FTL_EI_CRASH] = E.crash; ei[FTL_EI_IN_BOX] = E.is_in_box; ei[FTL_EI_ON_TRACE] = E.is_on_trace;
@@ -201,12 +201,12 @@ __device__ __forceinline__ void g_store(const FtlDevParams& P, GCtx& E) {
         if ((E.err_acc | E.error) != 0) atomicOr(&ei[FTL_EI_ERROR_STICKY], E.err_acc | E.error);
     }
     if (E.r < P.R) {
-        size_t ro = (size_t)E.env * P.R + E.r;
-        P.rb_pos[2 * ro] = E.rb.px; P.rb_pos[2 * ro + 1] = E.rb.py;
-        double* rd = P.rb_dbl + ro * FTL_RD_COUNT;
+        float* rp = rec_field(P.rb_pos, P, E.env) + 2 * E.r;
+        rp[0] = E.rb.px; rp[1] = E.rb.py;
+        double* rd = rec_field(P.rb_dbl, P, E.env) + E.r * FTL_RD_COUNT;
         rd[FTL_RD_DIRECTION] = E.rb.direction; rd[FTL_RD_SPEED] = E.rb.speed; rd[FTL_RD_ROT_SPEED] = E.rb.rot_speed;
         rd[FTL_RD_DES_SPEED] = E.rb.des_speed; rd[FTL_RD_DES_ROT_SPEED] = E.rb.des_rot_speed;
-        int4* ri = reinterpret_cast<int4*>(P.rb_int + ro * FTL_RI_COUNT);
+        int4* ri = reinterpret_cast<int4*>(rec_field(P.rb_int, P, E.env) + E.r * FTL_RI_COUNT);
         ri[0] = make_int4(E.rb.rx, E.rb.ry, E.rb.rw, E.rb.rh); ri[1] = make_int4(E.rb.rot_dir, E.rb.des_rot_dir, 0, 0);
         if (E.r >= 2) {
             int b = E.r - 2;
@@ -242,7 +242,7 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         E.green_count = 0; E.green_len = -1; E.green_w = 0.0; E.green_tiny = 0; E.error = 0; E.scan_ok = 0;
         E.trk_counter = 0; E.corr_lo = 0; E.corr_hi = 0; E.seed_end = 0; E.snap_count = 0; E.snap_head = 0;
         E.hint = 0; E.hx = 3.0e38f; E.hy = 3.0e38f; E.clr_g = 0.0f; E.clr_a = 0.0f;     // no cached point, no bound
-        if (c.has_tracker == 1 && E.r == 0) P.env_int[(size_t)E.env * FTL_EI_COUNT + FTL_EI_HIST1_LEN] = 0;   // v1 tracker reset(), SEN:223-226
+        if (c.has_tracker == 1 && E.r == 0) rec_field(P.env_int, P, E.env)[FTL_EI_HIST1_LEN] = 0;   // v1 tracker reset(), SEN:223-226
         if (c.rand_fps_hi > 0 && E.fps == 0) E.fps = d_rand_frames(c, E.env, 0, 0);      // the constructor's draw (ENV:405)
         E.cur_mult = 1.0; E.cur_acc = 0.0; E.cum_speed = 0.0; E.resets += 1;      // ENV:449, 591-592; acc_consumed persists (ENV:1170)
     }
@@ -1139,7 +1139,7 @@ __device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
                     }
                 } else {                                              // sensors.py:286
                     int oldest = E.corr_lo;               // the ring must still hold every point a stored snapshot refers to
-                    const int* sw = P.snap_win + (size_t)E.env * P.hmax * 4;
+                    const int* sw = rec_field(P.snap_win, P, E.env);
                     int nsnap = E.snap_count < P.hmax ? E.snap_count : P.hmax;
                     for (int j = 0; j < nsnap; j++) { int l0 = sw[4 * j], l1 = sw[4 * j + 2]; oldest = min(oldest, min(l0, l1)); }
                     if (E.corr_hi + 1 - oldest > c.corr_cap) { E.error |= FTL_ERR_CORR_OVERFLOW; save = false; }
@@ -1175,14 +1175,14 @@ __device__ __forceinline__ void g_sensors(const FtlDevParams& P, GCtx& E) {
         }
         if (g == 0) { w0lo = E.corr_lo; w0hi = E.corr_hi; }
     }
-    if (c.n_aux > 0 && w) { int* ei = P.env_int + (size_t)E.env * FTL_EI_COUNT; ei[FTL_EI_HW0_LO] = w0lo; ei[FTL_EI_HW0_HI] = w0hi; }
+    if (c.n_aux > 0 && w) { int* ei = rec_field(P.env_int, P, E.env); ei[FTL_EI_HW0_LO] = w0lo; ei[FTL_EI_HW0_HI] = w0hi; }
     E.scan_ok = ok;
     if (ok && E.valid) {             // one snapshot per step: dynamic rects + the corridor window each group saw
         int slot = E.snap_head;
-        int4* sr = reinterpret_cast<int4*>(P.snap_rects) + ((size_t)E.env * P.hmax + slot) * (P.R - 1);
+        int4* sr = reinterpret_cast<int4*>(rec_field(P.snap_rects, P, E.env)) + slot * (P.R - 1);
         if (E.r < P.R && E.r != 1) sr[E.r == 0 ? 0 : E.r - 1] = make_int4(E.rb.rx, E.rb.ry, E.rb.rw, E.rb.rh);
         if (E.r == 0) {
-            int* sw = P.snap_win + ((size_t)E.env * P.hmax + slot) * 4;
+            int* sw = rec_field(P.snap_win, P, E.env) + slot * 4;
             bool g0 = ok & 1;
             sw[0] = g0 ? w0lo : E.corr_lo; sw[1] = g0 ? w0hi : E.corr_hi; sw[2] = E.corr_lo; sw[3] = E.corr_hi;
         }
@@ -1276,7 +1276,7 @@ __global__ void __launch_bounds__(FTL_MT_THREADS) ftl_metrics_partial_kernel(con
         double* st = P.ep_stats + (size_t)e * FTL_N_METRICS;
 #pragma unroll
         for (int k = 0; k < FTL_N_METRICS; k++) { acc[k] += st[k]; if (clear) st[k] = 0.0; }
-        int* sticky = P.env_int + (size_t)e * FTL_EI_COUNT + FTL_EI_ERROR_STICKY;
+        int* sticky = rec_field(P.env_int, P, e) + FTL_EI_ERROR_STICKY;
         const int b = *sticky;
         if (b) { ecount += 1; ebits |= b; if (clear) *sticky = 0; }
     }
@@ -1456,7 +1456,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
             wt_reset = true;
 #endif
             if (go) { E.episodes += 1; E.err_acc |= E.error; }
-            g_reset<G>(P, E, go ? C.win_base + ((E.scen % C.win_count) + P.n_envs) % C.win_count : E.scen, go);
+            g_reset<G>(P, E, go ? C.win_base + ((E.scen % C.win_count) + C.win_stride) % C.win_count : E.scen, go);
             __syncthreads();
         }
     }
@@ -1467,7 +1467,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
     if (P.cfg.n_lasers > 0) {     // cos / sin of the follower's heading for the ray kernel: one sincos here serves the 16 envs of the wavefront
         double s, co;
         sincos_bounded(E.rb.direction * kDeg2Rad, s, co);
-        if (E.valid && E.r == 1) { P.fol_cs[2 * (size_t)E.env] = co; P.fol_cs[2 * (size_t)E.env + 1] = s; }
+        if (E.valid && E.r == 1) { double* fc = rec_field(P.fol_cs, P, E.env); fc[0] = co; fc[1] = s; }
     }
     FTL_TIC(7);
     g_write_obs<G>(P, C, E);                             // ENV:938

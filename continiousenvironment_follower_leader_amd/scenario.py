@@ -7,6 +7,7 @@ the choice among equal-cost routes (the reference's depends on object ids; see D
 import ctypes as C
 
 import numpy as np
+import torch
 
 from . import _lib, abi
 from .config import GameConfig
@@ -149,10 +150,19 @@ class ScenarioRing:
             else:
                 time.sleep(0.001)
 
+    def _stride(self, env):
+        """A step for the auto-reset's walk through a half that is coprime to its size (every entry gets visited) and close to n_envs
+        (the default walk of a plain pool)."""
+        import math
+        s = max(env.n % self.half, 1)
+        while math.gcd(s, self.half) != 1:
+            s += 1
+        return s
+
     def attach(self, env):
         """Load the ring's pool into ``env`` with the reset window on the first half."""
         env.load_scenarios(self.pool)
-        env.set_reset_window(0, self.half)
+        env.set_reset_window(0, self.half, self._stride(env))
 
     def poll(self, env, step):
         """Call between steps with the number of steps taken so far.  Starts the copy of a finished half into the inactive half once
@@ -165,7 +175,7 @@ class ScenarioRing:
                 self._left_at[self.active] = step
                 self.active = h
                 self._left_at[h] = None
-                env.set_reset_window(h * self.half, self.half)
+                env.set_reset_window(h * self.half, self.half, self._stride(env))
                 self.swaps += 1
                 if self.history is not None:
                     self.history.append((step, h, self._held))

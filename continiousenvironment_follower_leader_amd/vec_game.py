@@ -203,10 +203,11 @@ class VecGame:
         self.pool = pool
         _lib.check(self.lib.ftl_load_scenarios(self.h, C.byref(pool.c_struct)), self.lib)
 
-    def set_reset_window(self, base, count):
-        """Pool entries ``[base, base + count)`` the in-kernel auto-reset draws from (``ftl_set_reset_window``; the whole pool after
-        ``load_scenarios``): how a ``ScenarioRing`` hands freshly generated worlds to a running batch."""
-        _lib.check(self.lib.ftl_set_reset_window(self.h, int(base), int(count)), self.lib)
+    def set_reset_window(self, base, count, stride=0):
+        """Pool entries ``[base, base + count)`` the in-kernel auto-reset draws from and the step of its walk (``ftl_set_reset_window``;
+        the whole pool with stride n_envs after ``load_scenarios``): how a ``ScenarioRing`` hands freshly generated worlds to a running
+        batch.  ``stride`` should be coprime to ``count`` (0 keeps n_envs)."""
+        _lib.check(self.lib.ftl_set_reset_window(self.h, int(base), int(count), int(stride)), self.lib)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -340,12 +341,16 @@ class VecGame:
     def state_field(self, name):
         """Typed [n_envs, per_env] view of a named field of the state blob (parity tests / tracker obs)."""
         if name not in self._fields:
-            off, per, dt = C.c_size_t(), C.c_size_t(), C.c_int32()
-            _lib.check(self.lib.ftl_state_field(self.h, name.encode(), C.byref(off), C.byref(per), C.byref(dt)), self.lib)
+            off, per, dt, st = C.c_size_t(), C.c_size_t(), C.c_int32(), C.c_size_t()
+            _lib.check(self.lib.ftl_state_field(self.h, name.encode(), C.byref(off), C.byref(per), C.byref(dt), C.byref(st)), self.lib)
             tdt = _DT[dt.value]
             esz = torch.empty((), dtype=tdt).element_size()
             a = self._state_off + off.value
-            self._fields[name] = self.state[a:a + per.value * esz * self.n].view(tdt).view(self.n, per.value)
+            if per.value == 0:
+                self._fields[name] = torch.empty(self.n, 0, dtype=tdt, device=self.device)
+            else:      # rows of the per-env record are st bytes apart (a strided view), the long fields are dense
+                span = (self.n - 1) * st.value + per.value * esz
+                self._fields[name] = torch.as_strided(self.state[a:a + span + (-span) % esz].view(tdt), (self.n, per.value), (st.value // esz, 1))
         return self._fields[name]
 
     def tracker_obs(self, env):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FTL_ABI_VERSION 3
+#define FTL_ABI_VERSION 4
 #define FTL_MAX_BEARS 6   /* robots per env = 2 + bears <= 8 (one lane each in a group of the frame kernel); bears 5, 7, .. of
                              move_bear_v4 draw their way-points from `random` every frame (ENV:750-754): ftl_rand_range below */
 #define FTL_MAX_LASERS 4
@@ -297,21 +297,25 @@ int ftl_get_config(const ftl_handle* h, ftl_config* out);
 size_t ftl_state_bytes(const ftl_handle* h);
 int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes);
 
-/* State introspection for parity tests: byte offset / element count / dtype code of a named field
- * ("rb_pos","rb_dbl","rb_int","env_int","env_dbl","traj","traj_bb","hist","corr","snap_rects","snap_win").
- * dtype: 0 i32, 1 f32, 2 f64.  per_env = elements per env (fields are [n_envs][per_env]). */
-int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype);
+/* State introspection for parity tests: byte offset / element count / dtype code / row stride of a named field
+ * ("rb_pos","rb_dbl","rb_int","env_int","env_dbl","fol_cs","snap_rects","snap_win" -- the fields of the per-env record -- and
+ * "traj","traj_bb","hist","corr","ep_stats","hist1").  dtype: 0 i32, 1 f32, 2 f64.  Element j of env e sits at byte
+ * offset + e * stride + j * sizeof(dtype), j < per_env: the record fields share one stride (the record size, a multiple of 128), the
+ * others are dense [n_envs][per_env] arrays. */
+int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype, size_t* stride);
 
 /* reset() part 1 (ENV:461-492): hand over the scenario pool produced by reset-time generation. */
 int ftl_load_scenarios(ftl_handle* h, const ftl_scenarios* pool);
 
 /* The pool entries the in-kernel auto-reset (FTL_STEP_AUTO_RESET) draws from: a finished env that ran scenario s restarts from
- * base + ((s mod count) + n_envs) mod count.  ftl_load_scenarios sets the window to the whole pool (base 0, count n_scenarios), which is
- * the walk documented at FTL_STEP_AUTO_RESET.  A caller that refills one half of a double-sized pool while the envs draw from the other
+ * base + ((s mod count) + stride) mod count.  ftl_load_scenarios sets the window to the whole pool with stride n_envs (base 0, count
+ * n_scenarios), which is the walk documented at FTL_STEP_AUTO_RESET.  stride <= 0 keeps n_envs; a stride that shares a factor with count
+ * visits only part of the window (n_envs a multiple of count: the same scenario again and again, which turns the few worlds that start
+ * the follower inside a rock into one-step episodes forever) -- pick one that is coprime to count.  A caller that refills one half of a double-sized pool while the envs draw from the other
  * half (the reference builds a fresh world on every reset(), ENV:461-492; scenario.ScenarioRing) moves the window between steps; entries
  * outside the window stay valid for the episodes that are still running on them, so a half may be overwritten once every episode that
  * started before the window left it has ended (at most max_steps / frames_per_step + 1 steps). */
-int ftl_set_reset_window(ftl_handle* h, int32_t base, int32_t count);
+int ftl_set_reset_window(ftl_handle* h, int32_t base, int32_t count, int32_t stride);
 
 /* reset() (ENV:494-543): place env e at scenario scen_idx[e] for every e with mask[e] != 0 (mask NULL = all),
  * run the initial use_sensors (ENV:541) and write the first observation.  reward/done/status are zeroed. */

@@ -54,11 +54,22 @@ def test_create_validates_without_touching_the_device(lib):
     assert lib.ftl_create(C.byref(cfg.c), 4, 0, C.byref(h)) == 0
     try:
         assert lib.ftl_state_bytes(h) > 0 and lib.ftl_lasers_len(h) == 0
-        off, per, dt = C.c_size_t(), C.c_size_t(), C.c_int32()
-        for name, want in (("rb_pos", 1), ("rb_dbl", 2), ("env_int", 0), ("traj", 1), ("corr", 2), ("snap_win", 0)):
-            assert lib.ftl_state_field(h, name.encode(), C.byref(off), C.byref(per), C.byref(dt)) == 0
-            assert dt.value == want and off.value % 256 == 0 and per.value > 0
-        assert lib.ftl_state_field(h, b"nope", C.byref(off), C.byref(per), C.byref(dt)) == abi.FTL_E_INVALID
+        off, per, dt, st = C.c_size_t(), C.c_size_t(), C.c_int32(), C.c_size_t()
+        rec_stride, spans = None, []
+        for name, want, in_record in (("rb_pos", 1, True), ("rb_dbl", 2, True), ("rb_int", 0, True), ("env_int", 0, True), ("env_dbl", 2, True), ("fol_cs", 2, True),
+                                      ("snap_win", 0, True), ("snap_rects", 0, True), ("traj", 1, False), ("corr", 2, False), ("ep_stats", 2, False)):
+            assert lib.ftl_state_field(h, name.encode(), C.byref(off), C.byref(per), C.byref(dt), C.byref(st)) == 0
+            esz = (4, 4, 8)[dt.value]
+            assert dt.value == want and per.value > 0 and off.value % 16 == 0
+            if in_record:       # the small fields share one per-env record: a common stride (whole cache lines), disjoint byte ranges inside it
+                rec_stride = rec_stride or st.value
+                assert st.value == rec_stride and rec_stride % 128 == 0 and off.value + per.value * esz <= rec_stride
+                spans.append((off.value, off.value + per.value * esz))
+            else:               # the long fields are dense arrays behind the records
+                assert st.value == per.value * esz and off.value % 256 == 0 and off.value >= 4 * rec_stride
+        spans.sort()
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+        assert lib.ftl_state_field(h, b"nope", C.byref(off), C.byref(per), C.byref(dt), C.byref(st)) == abi.FTL_E_INVALID
         # call order is enforced before anything is launched
         out = abi.Outputs()
         assert lib.ftl_step(h, C.c_void_p(8), C.byref(out), 0, None) == abi.FTL_E_STATE

@@ -181,14 +181,14 @@ def test_scenario_ring_refills_while_stepping():
     pool = ScenarioPool.empty(cfg, 2 * half, "cuda:0")
     hist = list(ring.history)
     pool.write(0, hist[0][2]); torch.cuda.synchronize()
-    b.load_scenarios(pool); b.set_reset_window(0, half)
+    b.load_scenarios(pool); b.set_reset_window(0, half, ring._stride(b))
     b.reset(idx)
     # a half is copied some steps BEFORE it goes live; writing it at the step it goes live is only equivalent because no episode reads it in between
     for t in range(T):
         for (st, h, host) in hist[1:]:
             if st == t:
                 pool.write(h * half, host); torch.cuda.synchronize()
-                b.set_reset_window(h * half, half)
+                b.set_reset_window(h * half, half, ring._stride(b))
         b.step(acts[t], auto_reset=True)
         for x, y in zip(outs[t], (b.obs_num, b.lasers, b.reward, b.done, b.status)):
             assert torch.equal(x, y), t
