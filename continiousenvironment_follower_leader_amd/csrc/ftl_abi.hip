@@ -22,7 +22,7 @@ thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct Field { const char* name; size_t offset, per_env; int dtype; size_t stride; };     // stride: bytes from one env's row to the next
-constexpr int FTL_N_FIELDS = 14;
+constexpr int FTL_N_FIELDS = 15;
 
 }  // namespace
 
@@ -219,7 +219,8 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         {"hist", (size_t)cfg->corr_cap * 2, 2, 8, false}, {"corr", (size_t)cfg->corr_cap * 4, 2, 8, false},
         {"snap_rects", (size_t)hmax * (P.R - 1) * 4, 0, 4, true}, {"snap_win", (size_t)hmax * 4, 0, 4, true},
         {"traj_bb", (size_t)(cfg->traj_cap / FTL_TRAJ_BLOCK) * 4, 1, 4, false}, {"ep_stats", FTL_N_METRICS, 2, 8, false},
-        {"hist1", (size_t)(cfg->has_tracker == 1 ? cfg->hist1_cap : 0) * 2, 1, 4, false}, {"fol_cs", 2, 2, 8, true}};
+        {"hist1", (size_t)(cfg->has_tracker == 1 ? cfg->hist1_cap : 0) * 2, 1, 4, false}, {"fol_cs", 2, 2, 8, true},
+        {"corr32", (size_t)cfg->corr_cap * 4, 1, 4, false}};
     static const int rec_order[8] = {3 /*env_int*/, 13 /*fol_cs*/, 0 /*rb_pos*/, 1 /*rb_dbl*/, 9 /*snap_win*/, 8 /*snap_rects*/, 4 /*env_dbl*/, 2 /*rb_int*/};
     size_t ro = 0;
     for (int k = 0; k < 8; k++) {
@@ -324,7 +325,7 @@ int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes) {
     P.hist = (double*)(b + h->fields[6].offset); P.corr = (double*)(b + h->fields[7].offset);
     P.snap_rects = (int32_t*)(b + h->fields[8].offset); P.snap_win = (int32_t*)(b + h->fields[9].offset);
     P.traj_bb = (float*)(b + h->fields[10].offset); P.ep_stats = (double*)(b + h->fields[11].offset);
-    P.hist1 = (float*)(b + h->fields[12].offset); P.fol_cs = (double*)(b + h->fields[13].offset);
+    P.hist1 = (float*)(b + h->fields[12].offset); P.fol_cs = (double*)(b + h->fields[13].offset); P.corr32 = (float*)(b + h->fields[14].offset);
     h->bound = true; h->dirty = true;
     return FTL_OK;
 }

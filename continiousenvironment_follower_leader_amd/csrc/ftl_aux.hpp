@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256) ftl_tracker1_kernel(const FtlDevParams* _
                         double* q = corr_slot(P, env, clen);
                         q[0] = (c90 * vx + (-s90) * vy) + (double)p0.x; q[1] = (s90 * vx + c90 * vy) + (double)p0.y;
                         q[2] = (cm90 * vx + (-sm90) * vy) + (double)p0.x; q[3] = (sm90 * vx + cm90 * vy) + (double)p0.y;
+                        *corr32_slot(P, env, clen) = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
                         clen += 1;
                     }
                 }

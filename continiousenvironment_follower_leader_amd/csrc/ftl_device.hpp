@@ -62,6 +62,8 @@ struct FtlDevParams {
     float* traj; double* hist; double* corr; int32_t* snap_rects; int32_t* snap_win;
     float* traj_bb;                   // [n_envs][traj_cap / FTL_TRAJ_BLOCK][4]: xmin, ymin, xmax, ymax of each block of trajectory points
     double* ep_stats;                 // [n_envs][FTL_N_METRICS]: metrics of the episodes that ended in this env slot (include/ftl.h)
+    float* corr32;                    // [n_envs][corr_cap][4]: the corridor ring once more, in float32 -- what the ray kernel works with (sensors.py:672 casts
+                                      // the edges to float32); written with the float64 ring, half the bytes to read per scan
     float* hist1;                     // [n_envs][hist1_cap][2]: position history of the v1 tracker (sensors.py:148-229)
     double* fol_cs;                   // [n_envs][2]: cos, sin of the follower's direction as the frame kernel leaves it (one sincos per lane
                                       // there serves 16 envs; here it would be one per ray)
@@ -308,6 +310,9 @@ __device__ __forceinline__ double* hist_slot(const FtlDevParams& P, int env, int
 __device__ __forceinline__ double* corr_slot(const FtlDevParams& P, int env, int abs_idx) {
     return P.corr + ((size_t)env * P.cfg.corr_cap + (abs_idx & (P.cfg.corr_cap - 1))) * 4;
 }
+__device__ __forceinline__ float4* corr32_slot(const FtlDevParams& P, int env, int abs_idx) {
+    return reinterpret_cast<float4*>(P.corr32) + (size_t)env * P.cfg.corr_cap + (abs_idx & (P.cfg.corr_cap - 1));
+}
 // ---- LeaderCorridor_Prev_lasers_v2.scan (sensors.py:883-962): the rays ----------------------------------------------
 // Segment table entry classes (sensors.py:644-660): which sensors see an entry is decided per class
 enum { SEG_STATIC = 0, SEG_DYNAMIC = 1, SEG_CORRIDOR = 2, SEG_GREEN = 3, SEG_CLASSES = 4 };
@@ -521,7 +526,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
         // holds P.corr_lds_cap points; a longer span (rare) is not staged -- phase 3 then reads its corridor segments from the ring in
         // global memory, uncompacted (same values, same results).
         const bool staged = !CAPPED || umax - umin <= P.corr_lds_cap;
-        auto corr_f32 = [&](int p) { const double* q = corr_slot(P, env, p); return make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]); };
+        auto corr_f32 = [&](int p) { return *corr32_slot(P, env, p); };
         if (staged) for (int p = umin + lane; p < umax; p += FTL_WAVE) s_corr[p & cmask] = corr_f32(p);
         __syncthreads();
         FTL_RTIC(0);

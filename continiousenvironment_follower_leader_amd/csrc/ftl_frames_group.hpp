@@ -1069,7 +1069,10 @@ __device__ __forceinline__ void g_border_pair(const FtlDevParams& P, const GCtx&
     const double c90 = 6.123233995736766e-17, s90 = 1.0, cm90 = 6.123233995736766e-17, sm90 = -1.0;
     double r0 = (c90 * vx + (-s90) * vy) + a[0], r1 = (s90 * vx + c90 * vy) + a[1];
     double l0 = (cm90 * vx + (-sm90) * vy) + a[0], l1 = (sm90 * vx + cm90 * vy) + a[1];
-    if (write) { double* q = corr_slot(P, E.env, at); q[0] = r0; q[1] = r1; q[2] = l0; q[3] = l1; }
+    if (write) {
+        double* q = corr_slot(P, E.env, at); q[0] = r0; q[1] = r1; q[2] = l0; q[3] = l1;
+        *corr32_slot(P, E.env, at) = make_float4((float)r0, (float)r1, (float)l0, (float)l1);
+    }
 }
 
 // Both scans of a step for every env of the wave.  Memory written by one lane is read by the other lanes of its group

@@ -187,6 +187,9 @@ class ScenarioRing:
                 host, self._ready = self._ready, None
             if host is not None:
                 self._held = host        # keep the pinned buffers alive until the copy has landed
+                # `step` counts the steps the HOST has queued; the device may be many steps behind.  The copy must not overtake them:
+                # the side stream waits for everything queued on the batch's stream so far (steps that may still read this half).
+                self._stream.wait_stream(torch.cuda.current_stream(self.device))
                 self.pool.write(other * self.half, host, self._stream)
                 ev = torch.cuda.Event()
                 ev.record(self._stream)

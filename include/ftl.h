@@ -299,7 +299,7 @@ int ftl_bind_state(ftl_handle* h, void* dev_state, size_t bytes);
 
 /* State introspection for parity tests: byte offset / element count / dtype code / row stride of a named field
  * ("rb_pos","rb_dbl","rb_int","env_int","env_dbl","fol_cs","snap_rects","snap_win" -- the fields of the per-env record -- and
- * "traj","traj_bb","hist","corr","ep_stats","hist1").  dtype: 0 i32, 1 f32, 2 f64.  Element j of env e sits at byte
+ * "traj","traj_bb","hist","corr","corr32","ep_stats","hist1").  dtype: 0 i32, 1 f32, 2 f64.  Element j of env e sits at byte
  * offset + e * stride + j * sizeof(dtype), j < per_env: the record fields share one stride (the record size, a multiple of 128), the
  * others are dense [n_envs][per_env] arrays. */
 int ftl_state_field(const ftl_handle* h, const char* name, size_t* offset, size_t* per_env, int32_t* dtype, size_t* stride);
