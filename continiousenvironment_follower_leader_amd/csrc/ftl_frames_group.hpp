@@ -551,7 +551,7 @@ struct FrPend { float fpx, fpy; unsigned short n, gc, hint, key; };
 
 // REG = the config has leader regimes or random_frames_per_step: compiled apart (their mere presence cost the common kernel 2 %)
 template <int G, bool REG>
-__device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, const int4* s_near, int& tick, const bool first, const int f_idx,
+__device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Limits& L, double2& lead_cs, const int4* s_near, int& tick, const bool first, const int f_idx,
                                         unsigned char* s_rec, const int rec_stride, FrPend* s_pend, int* s_pcnt, bool& pend, int& pend_idx, float& new_ad) {
     const ftl_config& c = P.cfg;
     const int r = E.r;
@@ -576,6 +576,9 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
     // bears: way-point choice (ENV:722-758, 819-837)
     double tx = E.cur_tx, ty = E.cur_ty;
     const bool is_bear = act && r >= 2;
+#ifndef FTL_BEAR_SINCOS
+    const double lc = gb_d<G, 0>(lead_cs.x), ls = gb_d<G, 0>(lead_cs.y);      // (cross-lane reads stay outside the bears' branch: its lane 0 is inactive there)
+#endif
     if (is_bear) {
         const int b = r - 2;
         bool near = euclid_f64_lt((double)E.rb.px, (double)E.rb.py, E.rb.tgt_x, E.rb.tgt_y, c.leader_pos_epsilon);
@@ -595,7 +598,20 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             off = (E.rb.dyn_index == 0) ? -130.0 : 130.0;
         }
         double s, co;
+#ifdef FTL_BEAR_SINCOS
         sincos_bounded((ldir0 + off) * kDeg2Rad, s, co);
+#else
+        {   // rotateVector([lvl, 0], leader.direction + off) (ENV:730-737, 829-832): cos / sin of the sum by angle addition from the
+            // leader's own cos / sin -- its last move left them behind (lead_cs) -- and the offset's (130, 140 or 160 degrees, glibc
+            // values): 2-3 ulp from cos(radians(direction + off)), the class of the device's own sincos, for six
+            // multiplications instead of a seventy-operation dependent chain in front of the bears' steering
+            const double a = fabs(off);
+            const double ca = a == 130.0 ? -0.6427876096865394 : a == 140.0 ? -0.7660444431189779 : -0.9396926207859083;
+            const double sa0 = a == 130.0 ? 0.766044443118978 : a == 140.0 ? 0.6427876096865395 : 0.3420201433256689;
+            const double sa = off < 0.0 ? -sa0 : sa0;
+            co = lc * ca - ls * sa; s = ls * ca + lc * sa;
+        }
+#endif
         tx = (double)lpx0 + co * lvl; ty = (double)lpy0 + s * lvl;
         if (FTL_MAX_BEARS > 4 && drawn) {
             const int lo = (int)c.max_distance, k = 2 * E.rb.dyn_index;
@@ -639,7 +655,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         if (r == 0) { command_forward(E.rb, L, 0); command_turn(E.rb, L, 0, 0); }
     }
     bool moves = act && !(r == 0 && E.leader_finished);
-    robot_move(E.rb, L, moves);
+    robot_move(E.rb, L, moves, lead_cs.y, lead_cs.x);
 
     const float fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
     const int frx = gb_i<G, 1>(E.rb.rx), fry = gb_i<G, 1>(E.rb.ry), frw = gb_i<G, 1>(E.rb.rw), frh = gb_i<G, 1>(E.rb.rh);
@@ -1384,6 +1400,8 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         if (threadIdx.x == 0) *s_pcnt = 0;
         const bool defer = P.fr_defer != 0;              // the later frames' searches wait for the end of the step
         int sc = E.step_count;                           // step_count as the tail sees it (the frames advance E.step_count themselves)
+        double2 lead_cs;                                 // (cos, sin) of this lane's robot's direction as its last move left it: lane 0 = the leader's,
+        sincos_bounded(E.rb.direction * kDeg2Rad, lead_cs.y, lead_cs.x);   // which the bears' way-points are built from (g_frame)
         __syncthreads();
         FTL_TIC(5);
         int tick = (E.step_count + 1) % P.cfg.trajectory_saving_period;
@@ -1396,7 +1414,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
 #pragma nounroll
         for (int f = 0; f < f_max; f++) {
             bool pend = false; int pend_idx = -1; float new_ad = 3.0e38f;
-            if (!REG || f < E.fps) g_frame<G, REG>(P, E, L, near, tick, f == 0, f, s_rec, rec_stride, s_pend, s_pcnt, pend, pend_idx, new_ad);
+            if (!REG || f < E.fps) g_frame<G, REG>(P, E, L, lead_cs, near, tick, f == 0, f, s_rec, rec_stride, s_pend, s_pcnt, pend, pend_idx, new_ad);
             __syncthreads();          // an appended trajectory point is read by the other lanes of the group next frame
             // The pending searches.  After the first frame (and after every frame when nothing is deferred) every env searches for
             // itself: the next frames live on the caches these searches refresh.  After the last frame of a deferring step: everything
