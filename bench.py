@@ -330,7 +330,12 @@ def main():
         if ktimes:
             # the dominant kernel of the step
             dom = max(("frames", "rays", "aux"), key=lambda k: ktimes[k + "_us"])
-        kernel_ms = (ktimes["frames_us"] + ktimes["rays_us"] + ktimes["aux_us"] + ktimes["regroup_us"]) * 1e-3 if ktimes else step_ms
+        # One step = the launches of one ftl_step on one stream: the frame kernel, the ray kernel (+ ftl_aux_kernel, + the regroup kernels every
+        # 2nd step).  SURVEY 8(d)'s algorithmic bytes per env-step cover the whole step, so the roofline figure is bytes of one step / duration of
+        # one step, the duration from the HIP events around the timed region on the launch stream (step_ms_events).  kernels_us splits it per
+        # kernel from a separate pass with an event after every launch (each such event adds ~4.5 us of its own, which is why the parts exceed
+        # the whole: diagnostics, not the denominator).
+        kernel_ms = step_ms
         launch_bytes = bpe * n
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         prof = {}
@@ -342,8 +347,9 @@ def main():
                 prof = {}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": prof.get("hbm_bytes_per_step"), "traffic_source": prof.get("source"),
-                "kernel": "%s + %s (one step = both launches on one stream + the regroup kernels every 2nd step; HBM is the "
-                          "contract roofline, the ray kernel is VALU-issue bound -- see valu)" % knames,
+                "kernel": "%s + %s (one step = both launches on one stream + the regroup kernels every 2nd step; achieved = algorithmic bytes of a "
+                          "step / step duration from HIP events over the timed region; HBM is the contract roofline, the ray kernel is VALU-issue "
+                          "bound and the frame kernel latency bound -- see valu)" % knames,
                 "kernel_ms": kernel_ms, "step_ms_events": step_ms, "bytes_per_env_step": bpe,
                 "kernels_us": ktimes, "kernels_us_from": kmode if ktimes else None, "valu": prof.get("valu")}
         if ktimes:
