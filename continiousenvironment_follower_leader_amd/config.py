@@ -309,13 +309,15 @@ def make_config(game_width=1500, game_height=1000, framerate=500, frames_per_ste
             while cur < border:                      # SEN:95-101
                 cur += step
                 n_ang += 2
-            if spec.get("return_all_points", False):
-                raise NotImplementedError("LaserSensor(return_all_points=True) returns a ragged list (every marching point up to the first hit, "
-                                          "SEN:112-113): no fixed-shape batched output")
             only_d = bool(spec.get("return_only_distances", False))
+            all_pts = bool(spec.get("return_all_points", False))
             rng_px = spec.get("sensor_range", 5) * pixels_to_meter
-            aux.append(AuxSpec(name=name, kind=abi.AUX_LIDAR, shape=(n_ang,) if only_d else (n_ang, 2), after_tracker=seen_tracker,
-                               params=dict(n_angles=n_ang, points_number=int(spec.get("points_number", 20)), return_only_distances=int(only_d),
+            npts = int(spec.get("points_number", 20))
+            # return_all_points (SEN:112-113, 131-134): the scan returns every marching point up to the first hit of every ray -- K rows, K
+            # changing from call to call; the batched block is [K][K points or distances][zeros] (the facade cuts it back to K rows)
+            shape = ((1 + n_ang * npts * (1 if only_d else 2),) if all_pts else ((n_ang,) if only_d else (n_ang, 2)))
+            aux.append(AuxSpec(name=name, kind=abi.AUX_LIDAR, shape=shape, after_tracker=seen_tracker,
+                               params=dict(n_angles=n_ang, points_number=npts, return_only_distances=int(only_d), return_all_points=int(all_pts),
                                            range_px=float(rng_px), in_range_px=float(rng_px + 3 * pixels_to_meter), angle_step=float(step),
                                            border_angle=border)))
         elif cls in ("LeaderTrackDetector_vector", "LeaderTrackDetector_radar"):       # SEN:342-487

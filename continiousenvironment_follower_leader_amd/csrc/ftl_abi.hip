@@ -81,7 +81,7 @@ int validate(const ftl_config& c, std::string& why) {
         const ftl_aux_cfg& a = c.aux[j];
         REQ(a.kind >= FTL_AUX_LIDAR && a.kind <= FTL_AUX_TRACK_RADAR, "aux %d: unknown sensor kind", j);
         if (a.kind == FTL_AUX_LIDAR) {
-            REQ(a.n_angles > 0 && a.n_angles <= 512 && a.points_number > 0 && a.range_px > 0 && !a.return_all_points, "aux %d: bad lidar parameters", j);
+            REQ(a.n_angles > 0 && a.n_angles <= 512 && a.points_number > 0 && a.range_px > 0, "aux %d: bad lidar parameters", j);
             // the (ray, marching point) index of the lidar is split with a float quotient that is exact below 2^16 items (ftl_aux.hpp)
             REQ(a.points_number <= 1024 && a.n_angles * a.points_number < 65536, "aux %d: lidar with more than 1024 points per ray or 65535 (ray, point) pairs", j);
         }
@@ -161,7 +161,8 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
     }
     for (int j = 0; j < cfg->n_aux; j++) {       // lidar / detector blocks follow the ray sensors' blocks
         ftl_aux_cfg& a = P.cfg.aux[j];
-        a.out_len = a.kind == FTL_AUX_LIDAR ? a.n_angles * (a.return_only_distances ? 1 : 2) : a.kind == FTL_AUX_TRACK_VECTOR ? 2 * a.seq_len : a.radar_sectors;
+        a.out_len = a.kind == FTL_AUX_LIDAR ? (a.return_all_points ? 1 + a.n_angles * a.points_number * (a.return_only_distances ? 1 : 2) : a.n_angles * (a.return_only_distances ? 1 : 2))
+                  : a.kind == FTL_AUX_TRACK_VECTOR ? 2 * a.seq_len : a.radar_sectors;
         a.out_offset = off; off += a.out_len;
     }
     P.lasers_len = off; P.total_rays = rays; P.hmax = hmax;

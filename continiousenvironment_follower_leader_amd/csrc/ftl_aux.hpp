@@ -363,6 +363,33 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_AUX_WPE) ftl_aux_kernel(const Ft
                 if (hit) atomicMin(&s_first[a], i);
             }
             __syncthreads();
+            if (A.return_all_points) {
+                // SEN:112-113, 131-134: every marching point of a ray up to and including its first hit (all of them without a hit), rays in
+                // order: [count K][K points or distances][zeros].  Offsets of the rays by a running sum (a few hundred rays at most: lane 0),
+                // the points themselves -- the same float32 convex combinations the march tests -- by the whole wavefront.
+                const int wd = A.return_only_distances ? 1 : 2;
+                int* s_off = s_list;                                               // (the list of marched rays is not needed any more)
+                __syncthreads();
+                if (lane == 0) {
+                    int k = 0;
+                    for (int a = 0; a < n_ang; a++) { s_off[a] = k; k += s_first[a] != 0x7fffffff ? s_first[a] + 1 : npts; }
+                    s_cnt[0] = k;
+                }
+                __syncthreads();
+                const int K = s_cnt[0];
+                if (lane == 0) out[0] = (float)K;
+                for (int w = lane; w < n_ang * npts; w += FTL_WAVE) {
+                    const int a = (int)(((float)w + 0.5f) * inv_npts), i = w - a * npts;
+                    const int cnt_a = s_first[a] != 0x7fffffff ? s_first[a] + 1 : npts;
+                    if (i < cnt_a) {
+                        const float2 e = s_end[a], uu = s_u[i];
+                        const float dx = (e.x * uu.x + cxf * uu.y) - cxf, dy = (e.y * uu.x + cyf * uu.y) - cyf;
+                        const int at = s_off[a] + i;
+                        if (wd == 1) out[1 + at] = sqrtf(dx * dx + dy * dy); else { out[1 + 2 * at] = dx; out[2 + 2 * at] = dy; }
+                    }
+                }
+                for (int w = 1 + K * wd + lane; w < 1 + n_ang * npts * wd; w += FTL_WAVE) out[w] = 0.0f;
+            } else
             for (int a = lane; a < n_ang; a += FTL_WAVE) {
                 const float2 e = s_end[a];
                 float px = e.x, py = e.y;

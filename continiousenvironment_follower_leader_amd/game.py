@@ -161,7 +161,12 @@ class Game:
             elif cls == "FollowerInfo":
                 obs[name] = v.follower_info(name)[0].cpu().numpy().copy()   # [speed / max_speed, direction / 360] float32, SEN:834-842
             elif cls in ("LaserSensor", "LeaderTrackDetector_vector", "LeaderTrackDetector_radar"):
-                obs[name] = v.aux_view(name)[0].cpu().numpy().copy()        # float32 arrays, SEN:131-134, 381, 476
+                a = v.aux_view(name)[0].cpu().numpy().copy()                # float32 arrays, SEN:131-134, 381, 476
+                spec = next(x for x in self.cfg.aux if x.name == name)
+                if spec.params.get("return_all_points"):                    # [K][K rows][zeros] -> the K rows the reference's list holds
+                    k, w = int(a[0]), (1 if spec.params["return_only_distances"] else 2)
+                    a = a[1:1 + k * w].reshape((k,) if w == 1 else (k, 2))
+                obs[name] = a
             else:
                 a = v.laser_view(name)[0].cpu().numpy().copy()            # [max_prev_obs, lasers_count] float32, SEN:958
                 spec = next(l for l in self.cfg.lasers if l.name == name)

@@ -103,7 +103,10 @@ typedef struct ftl_aux_cfg {
     /* lidar */
     int32_t n_angles;             /* 1 + 2 * (number of angle_step increments until border_angle is reached), SEN:88-101 */
     int32_t points_number;
-    int32_t return_all_points;    /* out = [n_angles * points_number][2] marching points instead of [n_angles][2] */
+    int32_t return_all_points;    /* the scan returns EVERY marching point up to and including the first hit of every ray (all points_number of a ray
+                                     without a hit), rays in order, as the reference's list does (SEN:112-113, 131-134) -- an array whose length K
+                                     changes from call to call: out = [K as a float][K points (x, y) or K distances][zeros] in a block of
+                                     1 + n_angles * points_number * (2 or 1) floats */
     int32_t return_only_distances; /* out = [n][1] norms instead of [n][2] offsets (SEN:131-134) */
     double  range_px;             /* sensor_range * PIXELS_TO_METER */
     double  in_range_px;          /* range_px + 3 * PIXELS_TO_METER: objects farther than this (distance_to_rect) are ignored, SEN:78-79 */

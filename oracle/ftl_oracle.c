@@ -801,6 +801,11 @@ static void lidar_scan(const ftlo_env* e, const ftl_aux_cfg* A, float* out) {
         if (dmin <= A->in_range_px) { rc[nin][0] = x; rc[nin][1] = y; rc[nin][2] = w; rc[nin][3] = h; nin++; }
     }
     const float x1 = f->px, y1 = f->py;
+    /* return_all_points (SEN:112-113): every marching point up to and including the first hit goes to the list, nothing else; the block is
+     * [count][points or distances][zeros] */
+    const int wd = A->return_only_distances ? 1 : 2;
+    int K = 0;
+    if (A->return_all_points) for (int i = 0; i < 1 + A->n_angles * A->points_number * wd; i++) out[i] = 0.0f;
     for (int a = 0; a < A->n_angles; a++) {
         /* SEN:88-101: -direction, then +- k * angle_step (angle_correction on those) */
         double angle = -f->direction;
@@ -812,15 +817,22 @@ static void lidar_scan(const ftlo_env* e, const ftl_aux_cfg* A, float* out) {
         for (int i = 0; i < A->points_number; i++) {
             const double u = (double)i / (double)A->points_number;
             const float cx = x2 * (float)u + x1 * (float)(1.0 - u), cy = y2 * (float)u + y1 * (float)(1.0 - u);
+            if (A->return_all_points) {
+                const float ddx = cx - x1, ddy = cy - y1;
+                if (wd == 1) out[1 + K] = sqrtf(ddx * ddx + ddy * ddy); else { out[1 + 2 * K] = ddx; out[2 + 2 * K] = ddy; }
+                K++;
+            }
             int hit = 0;
             for (int o = 0; o < nin && !hit; o++)         /* Rect.collidepoint: x <= px < x + w and y <= py < y + h */
                 hit = (float)rc[o][0] <= cx && cx < (float)(rc[o][0] + rc[o][2]) && (float)rc[o][1] <= cy && cy < (float)(rc[o][1] + rc[o][3]);
             if (hit) { ptx = cx; pty = cy; break; }
         }
         const float dx = ptx - x1, dy = pty - y1;         /* sensed_points - position, float32 */
+        if (A->return_all_points) continue;
         if (A->return_only_distances) out[a] = sqrtf(dx * dx + dy * dy);
         else { out[2 * a] = dx; out[2 * a + 1] = dy; }
     }
+    if (A->return_all_points) out[0] = (float)K;
     free(rc);
 }
 
@@ -916,7 +928,8 @@ ftlo_env* ftlo_create(const ftl_config* cfg) {
     for (int k = 0; k < cfg->n_lasers; k++) { e->cfg.lasers[k].out_offset = off; off += cfg->lasers[k].history * laser_width(&cfg->lasers[k]); }
     for (int j = 0; j < cfg->n_aux; j++) {       /* lidar / detector blocks follow the ray sensors' blocks */
         ftl_aux_cfg* a = &e->cfg.aux[j];
-        a->out_len = a->kind == FTL_AUX_LIDAR ? a->n_angles * (a->return_only_distances ? 1 : 2) : a->kind == FTL_AUX_TRACK_VECTOR ? 2 * a->seq_len : a->radar_sectors;
+        a->out_len = a->kind == FTL_AUX_LIDAR ? (a->return_all_points ? 1 + a->n_angles * a->points_number * (a->return_only_distances ? 1 : 2) : a->n_angles * (a->return_only_distances ? 1 : 2))
+                   : a->kind == FTL_AUX_TRACK_VECTOR ? 2 * a->seq_len : a->radar_sectors;
         a->out_offset = off; off += a->out_len;
     }
     e->lasers_len = off;

@@ -163,6 +163,15 @@ CONFIGS = {
         ("radar_near", {"sensor_class": "LeaderTrackDetector_radar", "detectable_positions": "near", "radar_sectors_number": 36}),
         ("radar_old", {"sensor_class": "LeaderTrackDetector_radar", "position_sequence_length": 12, "radar_sectors_number": 18}),
         ("LeaderCorridor_lasers_all", dict(SENSORS_B["LeaderCorridor_lasers_all"]))])), post=None),
+    # config L_all: LaserSensor(return_all_points=True) -- every marching point up to the first hit of every ray (SEN:112-113, 131-134), once as
+    # points and once as distances, next to the sensors of B (two bears so that the lidars see moving rects)
+    "L_all": dict(kwargs=dict(bear_number=2, follower_sensors=OrderedDict([
+        ("LeaderPositionsTracker_v2", dict(SENSORS_B["LeaderPositionsTracker_v2"])),
+        ("lidar_all", {"sensor_class": "LaserSensor", "available_angle": 120, "angle_step": 20, "points_number": 8, "sensor_range": 3,
+                       "return_all_points": True}),
+        ("lidar_all_d", {"sensor_class": "LaserSensor", "available_angle": 360, "angle_step": 45, "points_number": 12, "sensor_range": 5,
+                         "return_all_points": True, "return_only_distances": True}),
+        ("LeaderCorridor_lasers_all", dict(SENSORS_B["LeaderCorridor_lasers_all"]))])), post=None),
     # config T: the deprecated v1 tracker (SEN:148-229; scanned once per step, corridor half-width max_dev, eat_close_points) feeding a
     # lasers_v2 sensor, a LeaderCorridor_lasers one and both detectors (a Prev_lasers_v2 sensor raises at reset on this tracker: its
     # corridor holds one pair after the first scan, SEN:893/962)
@@ -361,6 +370,15 @@ def obs_record(g, obs, laser_names):
         if v.get("sensor_class", n) in ("LaserSensor", "LeaderTrackDetector_vector", "LeaderTrackDetector_radar"):
             a = np.asarray(obs[n])
             assert a.dtype == np.float32, (n, a.dtype)
+            if v.get("sensor_class", n) == "LaserSensor" and v.get("return_all_points", False):
+                # K rows, K changing from step to step (SEN:112-113): stored in the batched layout [K][rows][zeros] (include/ftl.h)
+                sens = g.follower.sensors[n]
+                n_ang = 1 + 2 * len(np.arange(0, int(sens.available_angle / 2), sens.angle_step))
+                cap = n_ang * sens.points_number * (1 if sens.return_only_distances else 2)
+                blk = np.zeros(1 + cap, np.float32)
+                blk[0] = len(a)
+                blk[1:1 + a.size] = a.reshape(-1)
+                a = blk
             rec["aux:" + n] = a.copy()
     return rec
 
@@ -563,6 +581,8 @@ EPISODES = [
     ("C_s5_random", "C", 5, "random", 100),
     ("L_s2_chase", "L", 2, "chase", 150),
     ("L_s7_random", "L", 7, "random", 100),
+    ("Lall_s2_chase", "L_all", 2, "chase", 150),
+    ("Lall_s7_ram", "L_all", 7, "ram_rocks", 120),
     ("T_s3_chase", "T", 3, "chase", 200),
     ("T_s9_random", "T", 9, "random", 100),
     ("Bshort_s4_chase", "B_short", 4, "chase", 60),

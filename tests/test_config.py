@@ -57,7 +57,6 @@ def test_sensor_registry_and_dict_order():
     (dict(multiple_end_points=True, path_finding_algorythm="astar"), NotImplementedError),   # ENV:239-243
     (dict(follower_sensors={"x": {"sensor_class": "LeaderCorridor_Prev_lasers_v2", "lasers_count": 13, "max_prev_obs": 5}}), ValueError),  # SEN:761-762
     (dict(follower_sensors={"mystery": {}}), ValueError),                            # CLS:249
-    (dict(follower_sensors={"LaserSensor": {"return_all_points": True}}), NotImplementedError),   # ragged output (SEN:112-113)
     (dict(follower_sensors={"LeaderTrackDetector_radar": {}}), ValueError),          # CLS:240-243: no tracker registered
     (dict(follower_sensors={"c": {"sensor_class": "LeaderCorridor_lasers_compas", "max_prev_obs": 5}}), ValueError),   # SEN:1148-1151: flags
     (dict(follower_sensors={"c": {"sensor_class": "LeaderCorridor_Prev_lasers_v3", "max_prev_obs": 5}}), ValueError),  # SEN:993
@@ -105,6 +104,15 @@ def test_corridor_ring_capacity_follows_the_point_spacing():
         assert make_config(**dict(kw, frames_per_step=5)).c.corr_cap == 128                 # points twice as dense
         assert make_config(**dict(kw, frames_per_step=3)).c.corr_cap == 256
         assert make_config(**dict(kw, corr_cap=100)).c.corr_cap == 128                      # an explicit value is rounded up to a power of two
+
+
+def test_lidar_return_all_points_block():
+    """LaserSensor(return_all_points=True) (SEN:112-113, 131-134): the batched block is [K][K rows][zeros], sized for every marching point."""
+    cfg = make_config(follower_sensors={"LaserSensor": {"return_all_points": True, "available_angle": 90, "angle_step": 30, "points_number": 6}})
+    a = cfg.aux[0]
+    assert a.params["return_all_points"] == 1 and a.params["n_angles"] == 5 and a.shape == (1 + 5 * 6 * 2,) and cfg.lasers_len == 61
+    cfg = make_config(follower_sensors={"LaserSensor": {"return_all_points": True, "return_only_distances": True, "points_number": 4}})
+    assert cfg.aux[0].shape == (1 + 37 * 4,)
 
 
 def test_unknown_kwargs_are_swallowed_like_the_reference():

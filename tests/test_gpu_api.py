@@ -68,7 +68,7 @@ def test_game_facade_replays_a_reference_episode():
 
 
 @pytest.mark.parametrize("name", ["B_s3_chase_noisy", "E_s5_random", "D_s2_chase", "F_s7_chase", "G_s2_chase", "C_s1_chase", "L_s2_chase",
-                                  "T_s3_chase", "Bastar_s1_chase", "B6_s2_chase"])
+                                  "T_s3_chase", "Bastar_s1_chase", "B6_s2_chase", "Lall_s7_ram"])
 def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
     """The whole drop-in: Game(**kwargs); seed(s); reset(); step(a)... reproduces the reference's episode with the
     scenario built by the host-side generator from the python seed alone (nothing captured from the reference)."""
@@ -94,6 +94,9 @@ def test_game_facade_seed_reset_step_without_any_captured_scenario(name):
             assert obs[fname].dtype == np.float32 and np.array_equal(obs[fname], z["obs:finfo:" + fname][t])
         for a in g.cfg.aux:                    # LaserSensor / LeaderTrackDetector_vector / _radar: float32 arrays of the reference's shapes
             ref = z["obs:aux:" + a.name][t]
+            if a.params.get("return_all_points"):      # stored as [K][rows][zeros]; the facade returns the K rows the reference's list holds
+                k, w = int(ref[0]), (1 if a.params["return_only_distances"] else 2)
+                ref = ref[1:1 + k * w].reshape((k,) if w == 1 else (k, 2))
             assert obs[a.name].dtype == np.float32 and obs[a.name].shape == ref.shape and close(obs[a.name], ref).all(), (t, a.name)
     # the obs dict has the reference's keys in dict order; the v1 tracker's own entry is skipped by use_sensors (CLS:269-270)
     sens = kw["follower_sensors"]
