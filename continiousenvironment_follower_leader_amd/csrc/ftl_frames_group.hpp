@@ -246,8 +246,44 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
         if (c.rand_fps_hi > 0 && E.fps == 0) E.fps = d_rand_frames(c, E.env, 0, 0);      // the constructor's draw (ENV:405)
         E.cur_mult = 1.0; E.cur_acc = 0.0; E.cum_speed = 0.0; E.resets += 1;      // ENV:449, 591-592; acc_consumed persists (ENV:1170)
     }
+    // The initial trajectory (83-261 points).  When only a few envs of the wavefront reset -- the in-kernel auto-reset: one in most such
+    // steps -- the WHOLE wavefront copies them, one env at a time: up to 192 points per memory round trip instead of 32 per trip by the
+    // env's four lanes (five dependent trips: a third of what a reset cost its wavefront, and a wavefront with a reset is what a small
+    // batch's frame kernel waits for).  With many (an explicit reset of every env) the groups copy side by side as before.
+    const unsigned long long rmask = __ballot(go && E.r == 0);
+    const bool wide_copy = __popcll(rmask) <= 4;
+    if (wide_copy) {
+        unsigned long long need = rmask;
+        while (need) {
+            const int Lr = __ffsll((long long)need) - 1; need &= need - 1;
+            const int envL = __builtin_amdgcn_readlane(E.env, Lr), scenL = __builtin_amdgcn_readlane(scen, Lr), n0L = __builtin_amdgcn_readlane(init_n0, Lr);
+            const float2* src = reinterpret_cast<const float2*>(P.scen.init_traj) + (size_t)scenL * c.init_traj_cap;
+            float2* dst = reinterpret_cast<float2*>(P.traj + (size_t)envL * c.traj_cap * 2);
+            float4* bbw = reinterpret_cast<float4*>(P.traj_bb) + (size_t)envL * (c.traj_cap / FTL_TRAJ_BLOCK);
+            const int lane = threadIdx.x & (FTL_WAVE - 1);
+            for (int base = 0; base < n0L; base += 3 * FTL_WAVE) {
+                float2 q[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) { const int k = base + t * FTL_WAVE + lane; q[t] = src[k < n0L ? k : n0L - 1]; }
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const int k = base + t * FTL_WAVE + lane;
+                    const bool v = k < n0L;
+                    if (v) dst[k] = q[t];
+                    float4 box = v ? make_float4(q[t].x, q[t].y, q[t].x, q[t].y) : make_float4(3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f);
+#pragma unroll
+                    for (int off = FTL_TRAJ_BLOCK / 2; off >= 1; off >>= 1) {      // a block of 32 points = half a wavefront
+                        box.x = fminf(box.x, __shfl_xor(box.x, off)); box.y = fminf(box.y, __shfl_xor(box.y, off));
+                        box.z = fmaxf(box.z, __shfl_xor(box.z, off)); box.w = fmaxf(box.w, __shfl_xor(box.w, off));
+                    }
+                    const int k0 = base + t * FTL_WAVE + (lane & ~(FTL_TRAJ_BLOCK - 1));     // first point of this lane's block
+                    if ((lane & (FTL_TRAJ_BLOCK - 1)) == 0 && k0 < n0L) bbw[k0 / FTL_TRAJ_BLOCK] = box;
+                }
+            }
+        }
+    }
     // group-uniform from here on (go is the same in every lane of a group), so the broadcasts are safe
-    if (go) {
+    if (go && !wide_copy) {
         // The initial trajectory, one block of FTL_TRAJ_BLOCK points at a time: every lane loads its 32 / G points (all loads in flight
         // before the first store -- a load / store loop of possibly aliasing pointers pays one memory round trip per point, 20 us per
         // reset), stores them, and the block's bounding box (search acceleration, see g_range_argmin) comes from the same registers by a
