@@ -221,7 +221,10 @@ template <int G>
 __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen, bool go) {
     const ftl_config& c = P.cfg;
     int init_n0 = 0; const float2* init_src = nullptr; float2* init_dst = nullptr;
-    if (go) {
+    double2 rt01[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};      // the route's first two way-points: requested with the rest of the
+    if (go) {                                                                // scenario's header (one memory round trip), chosen below
+        const double2* rt = reinterpret_cast<const double2*>(P.scen.route + (size_t)scen * c.route_cap * 2);
+        rt01[0] = rt[0]; rt01[1] = rt[1];
         E.scen = scen;
         int rr = (E.r < P.R) ? E.r : 0;
         size_t so = (size_t)scen * P.R + rr;
@@ -315,9 +318,8 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
     }
     float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py);
     if (go) {
-        const double* rt = P.scen.route + (size_t)scen * c.route_cap * 2;
         if (E.route_len == 0) { E.done = 1; E.cur_tx = (double)lpx; E.cur_ty = (double)lpy; }
-        else { int id = E.route_len > 1 ? 1 : 0; E.cur_tx = rt[2 * id]; E.cur_ty = rt[2 * id + 1]; }
+        else { const double2 w = E.route_len > 1 ? rt01[1] : rt01[0]; E.cur_tx = w.x; E.cur_ty = w.y; }
         // ENV:717-718: every bear starts from the LAST bear_start_position, (leader - 150, leader - 150) in float32
         E.rb.tgt_x = (double)(lpx - 150.0f); E.rb.tgt_y = (double)(lpy - 150.0f); E.rb.dyn_index = 0;
     }
