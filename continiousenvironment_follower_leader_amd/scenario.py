@@ -124,6 +124,8 @@ class ScenarioRing:
         keys = ("static_rects", "robot_pos", "robot_dir", "robot_rect", "route", "route_len", "init_traj", "init_traj_len")
         parts, have = [], 0
         while have < self.half:
+            if self._stop:
+                raise StopIteration("closed")
             seeds = list(self._take(self._seeds, self._chunk))
             if not seeds:
                 raise StopIteration("the seed iterator of a ScenarioRing ran dry")
@@ -197,4 +199,14 @@ class ScenarioRing:
         return False
 
     def close(self):
+        """Stop the generator thread and wait for it: a daemon thread killed at interpreter exit inside ftl_generate_scenarios would take
+        the process down (its std::threads are still joinable)."""
         self._stop = True
+        if self._worker.is_alive():
+            self._worker.join(timeout=60)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
