@@ -12,6 +12,6 @@ for r in csv.DictReader(open(sys.argv[1])):
 n = int(sys.argv[2])
 print("kernel,launches_counted,avg_ns,min_ns,max_ns,launches_total")
 for k, v in sorted(rows.items()):
-    m = n if ("frames_group" in k or "rays" in k) else max(1, n // 2)        # the regroup kernels run every second step
+    m = n if ("frames_group" in k or "rays" in k) else min(len(v), max(1, n // 4))        # the regroup kernels run every fourth step (every 2nd until round 3)
     w = v[-m:]
     print('"%s",%d,%.1f,%d,%d,%d' % (k, len(w), sum(w) / len(w), min(w), max(w), len(v)))
