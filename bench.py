@@ -39,6 +39,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# The batch of a rank is stepped as this many independent sub-batches of consecutive envs, each on its own stream of the process and never
+# joined inside the timed region (PipelinedVecGame; --parts 1: one batch on one stream).  Measured on one MI355X (profiles/r03_z_parts_sweep.txt):
+# 2 parts give +14 % on workload B at 65,536 envs, +7-9 % at 8,192-32,768, +6-12 % on D, E, F, C, L, T; 3 give no more; 4 side streams collapse.
+DEFAULT_PARTS = 2
 
 
 def bytes_per_env_step(cfg, G, Cn):
@@ -176,6 +180,9 @@ def main():
     ap.add_argument("--cpu-age", type=int, default=150, help="untimed ageing steps of the CPU baseline's population")
     ap.add_argument("--kernel-steps", type=int, default=100, help="steps of the per-kernel HIP-event pass after the timed region")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--parts", type=int, default=0,
+                    help="step the batch as this many independent sub-batches, each on its own stream of the process (PipelinedVecGame: one "
+                         "part's ray kernel runs beside another part's frame kernel); 1: one batch on one stream; 0: the workload's default")
     ap.add_argument("--ring", type=int, default=0, metavar="HALF",
                     help="draw the scenarios from a ScenarioRing of two halves of HALF entries that generator threads refill while the batch "
                          "steps (fresh worlds, as the reference's reset() builds them) instead of the fixed pool; reports the window moves")
@@ -214,7 +221,15 @@ def main():
     sh, scaling = shard.plan(a.workload, rank, world, a.scaling, a.total_envs, a.envs_per_gpu)
     n = sh.n
     cfg, pool, workload_text, bpe, knames = build_workload(a.workload, sh.lo, a.seed, device)
-    env = VecGame(n, device=device, config=cfg)
+    parts = a.parts if a.parts > 0 else DEFAULT_PARTS
+    if a.ring > 0:                                 # (the ring moves ONE handle's reset window)
+        parts = 1
+    parts = max(1, min(parts, n))
+    if parts > 1:
+        from continiousenvironment_follower_leader_amd.vec_game import PipelinedVecGame
+        env = PipelinedVecGame(n, parts=parts, device=device, config=cfg)
+    else:
+        env = VecGame(n, device=device, config=cfg)
     ring = None
     if a.ring > 0:
         from continiousenvironment_follower_leader_amd.scenario import ScenarioRing
@@ -256,6 +271,8 @@ def main():
         if ring is not None:
             ring.poll(env, k0 + k)
         env.step(acts[(k0 + k) % n_sets], auto_reset=True)
+    if parts > 1:
+        env.join()                             # the launch stream waits for every part's stream: ev1 closes the step of ALL envs
     ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -290,6 +307,8 @@ def main():
 
     # per-kernel durations: a separate pass on the same (still steady-state) population with HIP events around each launch
     ktimes, kmode = None, "HIP events around every launch of %d further steps on the same population" % a.kernel_steps
+    if parts > 1:
+        kmode += " with the %d parts run one after the other on one stream (each kernel timed alone; averages per launch = per part)" % parts
     if rank == 0 and a.kernel_steps > 0:
         tenv = env
         try:
@@ -361,6 +380,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_text % (n, pool.n), "workload_id": a.workload,
                        "envs_per_gpu": n, "total_envs": total_envs,
+                       "parts": parts, "stepping": ("%d independent sub-batches of consecutive envs, each on its own stream of the process, never joined inside the "
+                                                    "timed region (PipelinedVecGame; bit-identical to one batch, tests/test_gpu_api.py)" % parts) if parts > 1
+                                                   else "one batch on one stream",
                        "parallelism": "independent contiguous env shards x%d, %s%s" % (world, "the same total at every N" if scaling == "strong" else "a fixed batch per GPU",
                                                                                  " (gloo rehearsal)" if (world > 1 and a.backend == "gloo") else ""),
                        "age_steps": a.age,

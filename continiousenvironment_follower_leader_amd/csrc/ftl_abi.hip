@@ -254,7 +254,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
                            + rects * 8 + 32                   /* facing-edge list (u16 x 4 per rect) + edge counters */
                            + (size_t)FTL_PAIR_CAP * 2 + 16);  /* candidate list of phase 3 */
     }
-    {   // frame kernel LDS: near lists + their counters | frame records (one byte per env and frame) | pending position checks | slot -> env
+    {   // frame kernel LDS: near lists + their counters | frame records (one byte per env and frame) | pending position checks | slot -> env | block boxes
         const int epw = FTL_WAVE / (P.R <= 4 ? 4 : 8);
         const int f_max = cfg->rand_fps_hi > 0 ? cfg->rand_fps_hi - 1 : cfg->frames_per_step;
         // The searches of frames 1.. wait for the end of the step when the step is short enough for their items to sit in LDS and the frame
@@ -266,7 +266,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         P.fr_rec_stride = (int)align_up((size_t)f_max, 16);
         P.fr_rec_off = (int)o; o += (size_t)P.fr_rec_stride * epw;
         P.fr_pend_off = (int)o; o += (size_t)epw * (P.fr_defer ? f_max - 1 : 1) * 16;
-        P.fr_env_off = (int)o; o += (size_t)epw * 4 + 16;
+        P.fr_env_off = (int)o; o += (size_t)epw * 4 + 16 + (size_t)epw * 16;      // slot -> env, item counter, box of the trajectory block being filled
         P.fr_lds = (int)o;
         if (o > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "the frame kernel needs more than 64 KiB of LDS per wavefront (static rects x frames per step)"); }
     }

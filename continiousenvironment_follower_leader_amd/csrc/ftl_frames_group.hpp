@@ -145,24 +145,45 @@ struct GCtx {
     Robot rb;
 };
 
-template <int G>
+// The env scalars that no frame reads -- what the tail of frame_step, the tracker and the bookkeeping after the frame loop work on.
+// step() loads them AFTER the loop (g_load_late): held across it they cost the loop ~20 registers, which the compiler paid for with
+// scratch reloads inside the frames.  REG kernels keep the leader-regime state with the frames, which use it.
+template <bool REG>
+__device__ __forceinline__ void g_load_late(const FtlDevParams& P, GCtx& E) {
+    const int* ei = rec_field(P.env_int, P, E.env);
+    const double* ed = rec_field(P.env_dbl, P, E.env);
+    E.done = ei[FTL_EI_DONE]; E.crash = ei[FTL_EI_CRASH]; E.is_in_box = ei[FTL_EI_IN_BOX]; E.is_on_trace = ei[FTL_EI_ON_TRACE];
+    E.too_close = ei[FTL_EI_TOO_CLOSE]; E.finish_timer = ei[FTL_EI_FINISH_TIMER];
+    E.trk_counter = ei[FTL_EI_TRK_COUNTER]; E.corr_lo = ei[FTL_EI_CORR_LO];
+    E.corr_hi = ei[FTL_EI_CORR_HI]; E.seed_end = ei[FTL_EI_SEED_END]; E.snap_count = ei[FTL_EI_SNAP_COUNT];
+    E.episodes = ei[FTL_EI_EPISODES]; E.snap_head = ei[FTL_EI_SNAP_HEAD];
+    E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
+    if (!REG) {
+        E.acc_consumed = ei[FTL_EI_ACC_CONSUMED];
+        E.cur_mult = ed[FTL_ED_CUR_MULT]; E.cur_acc = ed[FTL_ED_CUR_ACC]; E.cum_speed = ed[FTL_ED_CUM_SPEED];
+    }
+}
+
+// LATE = leave the fields of g_load_late<REG> to a later call
+template <int G, bool LATE = false, bool REG = false>
 __device__ __forceinline__ void g_load(const FtlDevParams& P, GCtx& E) {
     const int* ei = rec_field(P.env_int, P, E.env);
     const double* ed = rec_field(P.env_dbl, P, E.env);
     E.scen = ei[FTL_EI_SCEN]; E.cur_target_id = ei[FTL_EI_TARGET_ID]; E.leader_finished = ei[FTL_EI_LEADER_FINISHED];
-    E.done = ei[FTL_EI_DONE]; E.crash = ei[FTL_EI_CRASH]; E.is_in_box = ei[FTL_EI_IN_BOX]; E.is_on_trace = ei[FTL_EI_ON_TRACE];
-    E.too_close = ei[FTL_EI_TOO_CLOSE]; E.step_count = ei[FTL_EI_STEP_COUNT]; E.finish_timer = ei[FTL_EI_FINISH_TIMER];
-    E.traj_len = ei[FTL_EI_TRAJ_LEN]; E.trk_counter = ei[FTL_EI_TRK_COUNTER]; E.corr_lo = ei[FTL_EI_CORR_LO];
-    E.corr_hi = ei[FTL_EI_CORR_HI]; E.seed_end = ei[FTL_EI_SEED_END]; E.snap_count = ei[FTL_EI_SNAP_COUNT];
-    E.error = ei[FTL_EI_ERROR]; E.episodes = ei[FTL_EI_EPISODES]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
-    E.snap_head = ei[FTL_EI_SNAP_HEAD]; E.hint = ei[FTL_EI_HINT]; E.green_tiny = ei[FTL_EI_GREEN_TINY];
-    E.resets = ei[FTL_EI_RESETS]; E.acc_consumed = ei[FTL_EI_ACC_CONSUMED];
+    E.step_count = ei[FTL_EI_STEP_COUNT];
+    E.traj_len = ei[FTL_EI_TRAJ_LEN];
+    E.error = ei[FTL_EI_ERROR]; E.green_count = ei[FTL_EI_GREEN_COUNT]; E.green_len = ei[FTL_EI_GREEN_LEN];
+    E.hint = ei[FTL_EI_HINT]; E.green_tiny = ei[FTL_EI_GREEN_TINY];
+    E.resets = ei[FTL_EI_RESETS];
     E.fps = P.cfg.rand_fps_hi > 0 ? ei[FTL_EI_FPS] : P.cfg.frames_per_step;
     E.hx = __int_as_float(ei[FTL_EI_HINT_X]); E.hy = __int_as_float(ei[FTL_EI_HINT_Y]);
     E.clr_g = __int_as_float(ei[FTL_EI_CLR_GREEN]); E.clr_a = __int_as_float(ei[FTL_EI_CLR_ALL]);
-    E.cur_mult = ed[FTL_ED_CUR_MULT]; E.cur_acc = ed[FTL_ED_CUR_ACC]; E.cum_speed = ed[FTL_ED_CUM_SPEED];
-    E.acc_penalty = ed[FTL_ED_ACC_PENALTY]; E.overall_reward = ed[FTL_ED_OVERALL_REWARD];
     E.cur_tx = ed[FTL_ED_SPARE0]; E.cur_ty = ed[FTL_ED_SPARE1]; E.green_w = ed[FTL_ED_GREEN_W];
+    if (!LATE || REG) {
+        E.acc_consumed = ei[FTL_EI_ACC_CONSUMED];
+        E.cur_mult = ed[FTL_ED_CUR_MULT]; E.cur_acc = ed[FTL_ED_CUR_ACC]; E.cum_speed = ed[FTL_ED_CUM_SPEED];
+    }
+    if (!LATE) g_load_late<true>(P, E);
     int rr = (E.r < P.R) ? E.r : 0;          // idle lanes mirror robot 0 (never committed)
     const float* rp = rec_field(P.rb_pos, P, E.env) + 2 * rr;
     E.rb.px = rp[0]; E.rb.py = rp[1];
@@ -329,7 +350,7 @@ __device__ __forceinline__ void g_reset(const FtlDevParams& P, GCtx& E, int scen
 // A robot's hitbox stays inside pos +- ((w+h)/2 + 1) and pos moves at most frames*max_speed per step, so a rect outside
 // that swept box (plus slack) can never collide during the step: dropping it from the per-frame tests is exact.
 template <int G>
-__device__ __forceinline__ void g_build_near(const FtlDevParams& P, GCtx& E, int4* s_near, int* s_cnt) {
+__device__ __forceinline__ void g_build_near(const FtlDevParams& P, GCtx& E, int4* s_near, int* s_cnt, float4* s_box) {
     const ftl_config& c = P.cfg;
     const float lpx = gb_f<G, 0>(E.rb.px), lpy = gb_f<G, 0>(E.rb.py), fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
     const float F = (float)(c.rand_fps_hi > 0 ? c.rand_fps_hi : c.frames_per_step);     // most frames a step can have
@@ -340,6 +361,9 @@ __device__ __forceinline__ void g_build_near(const FtlDevParams& P, GCtx& E, int
     if (E.valid) {
         const int4* src = reinterpret_cast<const int4*>(P.scen.static_rects) + (size_t)E.scen * c.n_static;
         int4* dst = s_near + (size_t)E.slot * c.n_static;
+        // the bounding box of the trajectory block that the next appended point falls into travels with this round trip: the frames
+        // that append a point update it in LDS (s_box) instead of reading it back from memory, a dependent round trip each
+        const float4 box0 = (reinterpret_cast<const float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK))[min(E.traj_len, c.traj_cap - 1) / FTL_TRAJ_BLOCK];
         constexpr int SU = 8;                            // rects per lane in flight at once
         for (int s0 = 0; s0 < c.n_static; s0 += SU * G) {
             int4 qv[SU];
@@ -355,6 +379,7 @@ __device__ __forceinline__ void g_build_near(const FtlDevParams& P, GCtx& E, int
                 if (s < c.n_static && (nl || nf)) dst[atomicAdd(&s_cnt[E.slot], 1)] = q;
             }
         }
+        if (E.r == 0) s_box[E.slot] = box0;
     }
     __syncthreads();
     E.near_cnt = s_cnt[E.slot];
@@ -611,6 +636,7 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             E.cur_tx = rt[0]; E.cur_ty = rt[1];
         }
     }
+    FTL_TIC(13);
     // bears: way-point choice (ENV:722-758, 819-837)
     double tx = E.cur_tx, ty = E.cur_ty;
     const bool is_bear = act && r >= 2;
@@ -693,7 +719,9 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
         if (r == 0) { command_forward(E.rb, L, 0); command_turn(E.rb, L, 0, 0); }
     }
     bool moves = act && !(r == 0 && E.leader_finished);
+    FTL_TIC(14);
     robot_move(E.rb, L, moves, lead_cs.y, lead_cs.x);
+    FTL_TIC(15);
 
     const float fpx = gb_f<G, 1>(E.rb.px), fpy = gb_f<G, 1>(E.rb.py);
     const int frx = gb_i<G, 1>(E.rb.rx), fry = gb_i<G, 1>(E.rb.ry), frw = gb_i<G, 1>(E.rb.rw), frh = gb_i<G, 1>(E.rb.rh);
@@ -737,6 +765,8 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             const int o = nn - 2 - Gn;
             float2 p1 = tr[nn - 1], p0 = tr[nn - 2];
             float2 q0 = tr[max(o, 0)], q1 = tr[max(o + 1, 0)], q2 = tr[max(o + 2, 0)], q3 = tr[max(o + 3, 0)];
+            asm volatile("" :: "v"(q2.x), "v"(q2.y), "v"(q3.x), "v"(q3.y));    // all six loads before the first wait: left alone, the compiler moves the
+                                                                               // last two into the branches that use them, two more round trips
             const double d_beyond = euclid_f32(q1.x, q1.y, q0.x, q0.y), d_old1 = euclid_f32(q2.x, q2.y, q1.x, q1.y),
                          d_old2 = euclid_f32(q3.x, q3.y, q2.x, q2.y);
             const double d_new = euclid_f32(p1.x, p1.y, p0.x, p0.y);
@@ -844,9 +874,10 @@ __device__ __forceinline__ void g_frame(const FtlDevParams& P, GCtx& E, const Li
             if (E.valid && r == 0) {
                 float2* tw = reinterpret_cast<float2*>(P.traj + (size_t)E.env * c.traj_cap * 2); tw[E.traj_len] = make_float2(lpx, lpy);
                 float4* bb = reinterpret_cast<float4*>(P.traj_bb) + (size_t)E.env * (c.traj_cap / FTL_TRAJ_BLOCK) + E.traj_len / FTL_TRAJ_BLOCK;
-                float4 box = (E.traj_len % FTL_TRAJ_BLOCK == 0) ? make_float4(lpx, lpy, lpx, lpy) : *bb;
+                float4* s_box = reinterpret_cast<float4*>(s_pcnt + 4) + E.slot;       // the block's box so far (g_build_near)
+                float4 box = (E.traj_len % FTL_TRAJ_BLOCK == 0) ? make_float4(lpx, lpy, lpx, lpy) : *s_box;
                 box.x = fminf(box.x, lpx); box.y = fminf(box.y, lpy); box.z = fmaxf(box.z, lpx); box.w = fmaxf(box.w, lpy);
-                *bb = box;
+                *s_box = box; *bb = box;
             }
             {   // the new point enters the distance bounds
                 float ax = lpx - fpx, ay = lpy - fpy;
@@ -939,7 +970,11 @@ __device__ __forceinline__ int g_position_search(const ftl_config& c, const floa
         if (in_eps) { bits = FR_ON_TRACE | FR_IN_BOX; hint = gi; hx = q.x; hy = q.y; }
         else if (in_dev) { bits = FR_IN_BOX; hint = gi; hx = q.x; hy = q.y; }
         else if (wbest < eps2_lo) { bits = FR_ON_TRACE; hint = widx; hx = wp.x; hy = wp.y; }   // some point is within epsilon
+#ifdef FTL_ABLATE_WHOLE      // timing experiment only: what the whole-trajectory searches cost (results differ)
+        else if (fps != -12345) {
+#else
         else {                                             // closest point of the whole trajectory (ENV:1924-1930)
+#endif
             float ab2; int ai; float2 q2; float skip2;
             g_range_argmin<G>(tr, bb, r, fpx, fpy, 0, n, (float)(eps * eps * (1.0 + 1e-5)) + 1e-2f, false, widx, wbest, wp, ab2, ai, q2, skip2);
             clr_a = sqrtf(fmaxf(fminf(ab2, skip2), 0.0f)) * 0.999999f - 1e-3f;  // every trajectory point is at least this far
@@ -961,6 +996,9 @@ __device__ __forceinline__ void g_resolve(const FtlDevParams& P, const GCtx& E, 
                                           const int cnt, const bool spread, const int own, int& hint, float& hx, float& hy, float& clr_g, float& clr_a) {
     constexpr int EPW = FTL_WAVE / G;
     const ftl_config& c = P.cfg;
+#ifdef FTL_ABLATE_SPREAD     // timing experiment only: what the deferred searches cost (results differ)
+    if (spread) return;
+#endif
     for (int base = 0; base < (spread ? cnt : 1); base += EPW) {      // wave-uniform trip count
         const int k = spread ? base + E.slot : own;
         if (k >= 0 && k < cnt) {                                     // group-uniform
@@ -969,7 +1007,13 @@ __device__ __forceinline__ void g_resolve(const FtlDevParams& P, const GCtx& E, 
             const float2* tr = reinterpret_cast<const float2*>(P.traj + (size_t)env * c.traj_cap * 2);
             const float4* bb = reinterpret_cast<const float4*>(P.traj_bb) + (size_t)env * (c.traj_cap / FTL_TRAJ_BLOCK);
             hint = it.hint; hx = 3.0e38f; hy = 3.0e38f; clr_g = -1.0f; clr_a = -1.0f;
-            const int bits = g_position_search<G>(c, tr, bb, E.r, it.fpx, it.fpy, (int)it.n, (int)it.gc, spread ? c.frames_per_step : E.fps, hint, hx, hy, clr_g, clr_a);
+            const int bits = g_position_search<G>(c, tr, bb, E.r, it.fpx, it.fpy, (int)it.n, (int)it.gc,
+#ifdef FTL_ABLATE_WHOLE
+                                                     spread ? -12345 : E.fps,
+#else
+                                                     spread ? c.frames_per_step : E.fps,
+#endif
+                                                     hint, hx, hy, clr_g, clr_a);
             if (E.r == 0) {
                 unsigned char* rp = s_rec + oslot * rec_stride + frame;
                 *rp = (unsigned char)((*rp & ~(FR_PENDING | FR_IN_BOX | FR_ON_TRACE)) | bits);
@@ -1402,8 +1446,11 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
         }
         __syncthreads();
     } else {                                             // step(action): ENV:908-945
+#ifdef FTL_NO_LATE_LOAD
         g_load<G>(P, E);
-        const int done0 = E.done;
+#else
+        g_load<G, true, REG>(P, E);
+#endif
         FTL_TIC(4);
         // One memory round trip for everything the frames need besides the state: the action and the scenario's static rects
         // (culled into the near list).
@@ -1419,7 +1466,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
 
         // (this env's block bounding boxes stay in global memory: the searches that read them are rare -- an LDS copy per
         //  step measured 2 % slower than no copy once the search caches were in place, and cost 0.6 KB of traffic)
-        g_build_near<G>(P, E, s_near, s_cnt);
+        g_build_near<G>(P, E, s_near, s_cnt, reinterpret_cast<float4*>(lds + P.fr_env_off + EPW * 4 + 16));
         if (E.r == 1) {
             command_forward(E.rb, L, a0);                                   // ENV:927
             if (a1 < 0) command_turn(E.rb, L, fabs(a1), -1);                // ENV:928-933
@@ -1477,6 +1524,10 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_FRAMESG_WPE) ftl_frames_group_ke
             }
         }
         FTL_TIC(11);
+#ifndef FTL_NO_LATE_LOAD
+        g_load_late<REG>(P, E);
+#endif
+        const int done0 = E.done;
         // the tail of every frame (ENV:1077-1141), from the records
         const TailK TK = tail_consts(P.cfg);
 #pragma nounroll

@@ -141,7 +141,7 @@ class VecGame:
     ``[H_k, N_k]`` block per ray sensor, ``laser_view(name)``), ``target`` f64[N,2], ``reward`` f64[N],
     ``done`` u8[N], ``status`` u8[N,3] (mission/agent/leader codes of ``abi.MISSION/AGENT/LEADER``)."""
 
-    def __init__(self, n_envs, device="cuda:0", config: GameConfig = None, policy_obs=False, **game_kwargs):
+    def __init__(self, n_envs, device="cuda:0", config: GameConfig = None, policy_obs=False, _outputs=None, **game_kwargs):
         self.cfg = config if config is not None else make_config(**game_kwargs)
         self.n = int(n_envs)
         self.device = torch.device(device)
@@ -162,12 +162,19 @@ class VecGame:
         _lib.check(self.lib.ftl_bind_state(self.h, base + self._state_off, nbytes), self.lib)
         L = max(self.cfg.lasers_len, 1)
         z = dict(device=self.device)
-        self.obs_num = torch.zeros(self.n, abi.FTL_OBS_NUM, dtype=torch.float32, **z)
-        self.lasers = torch.zeros(self.n, L, dtype=torch.float32, **z)
-        self.target = torch.zeros(self.n, 2, dtype=torch.float64, **z)
-        self.reward = torch.zeros(self.n, dtype=torch.float64, **z)
-        self.done = torch.zeros(self.n, dtype=torch.uint8, **z)
-        self.status = torch.zeros(self.n, 3, dtype=torch.uint8, **z)
+        def out(name, *shape, dtype):          # an output tensor of this batch, or the rows of a larger one that the caller owns (PipelinedVecGame)
+            if _outputs is None:
+                return torch.zeros(self.n, *shape, dtype=dtype, **z)
+            t = _outputs[name]
+            if tuple(t.shape) != (self.n, *shape) or t.dtype != dtype or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("output tensor %r does not fit this batch" % name)
+            return t
+        self.obs_num = out("obs_num", abi.FTL_OBS_NUM, dtype=torch.float32)
+        self.lasers = out("lasers", L, dtype=torch.float32)
+        self.target = out("target", 2, dtype=torch.float64)
+        self.reward = out("reward", dtype=torch.float64)
+        self.done = out("done", dtype=torch.uint8)
+        self.status = out("status", 3, dtype=torch.uint8)
         o = abi.Outputs()
         o.obs_num, o.lasers, o.target = self.obs_num.data_ptr(), self.lasers.data_ptr(), self.target.data_ptr()
         o.reward, o.done, o.status = self.reward.data_ptr(), self.done.data_ptr(), self.status.data_ptr()
@@ -179,7 +186,7 @@ class VecGame:
         if policy_obs and sel:
             if len(hs) != 1:
                 raise ValueError("policy_obs needs the same max_prev_obs on every sensor it concatenates (wrappers.py:207, 217 assert it)")
-            self.policy_obs = torch.zeros(self.n, hs.pop(), sum(l.width for l in sel), dtype=torch.float32, **z)
+            self.policy_obs = out("policy_obs", hs.pop(), sum(l.width for l in sel), dtype=torch.float32)
             o.policy_obs = self.policy_obs.data_ptr()
         self._metrics = torch.zeros(abi.FTL_N_METRICS, dtype=torch.float64, **z)
         self._errors = torch.zeros(2, dtype=torch.int32, **z)
@@ -238,31 +245,36 @@ class VecGame:
         float tensor [N] (or [N,1]) of rotations: both are decoded on the device as ENV:909-925 does (``ftl_step_encoded``).
         ``check_errors=True`` synchronises and raises what the reference would have raised in any env (``raise_on_errors``);
         the default leaves the per-env sticky error words for ``error_report()`` so that the step stays asynchronous."""
+        action, enc = self._encode_action(action, self.n)
         flags = abi.FTL_STEP_AUTO_RESET if auto_reset else 0
-        enc = abi.FTL_ACTION_BOX2
-        if action.device != self.device:
-            raise ValueError("action must live on %s" % self.device)
-        if self.cfg.discrete_action_space or self.cfg.constant_follower_speed:
-            if tuple(action.shape) not in ((self.n,), (self.n, 1)):
-                raise ValueError("action must be [n_envs] or [n_envs, 1] for this action space (ENV:358-372)")
-            if self.cfg.discrete_action_space and self.cfg.constant_follower_speed:
-                # ENV:922 then ENV:925: np.concatenate([[0.25], (max_speed, rotation)]) -- the follower's max_speed ends up as the rotation
-                action = torch.tensor([0.25, self.cfg.c.follower.max_speed], dtype=torch.float64, device=self.device).repeat(self.n, 1)
-            elif self.cfg.discrete_action_space:
-                if action.dtype.is_floating_point or action.dtype == torch.bool:
-                    raise ValueError("Discrete(5) actions must be an integer tensor")
-                action, enc = action.reshape(self.n).to(torch.int32).contiguous(), abi.FTL_ACTION_DISCRETE
-            else:
-                if not action.dtype.is_floating_point:
-                    raise ValueError("Box(1) actions must be a float tensor")
-                action, enc = action.reshape(self.n).to(torch.float64).contiguous(), abi.FTL_ACTION_TURN
-            self._keep_action = action
-        elif action.dtype != torch.float64 or not action.is_contiguous() or tuple(action.shape) != (self.n, 2):
-            raise ValueError("action must be a contiguous float64 [n_envs, 2] tensor on %s" % self.device)
         _lib.check(self.lib.ftl_step_encoded(self.h, action.data_ptr(), enc, C.byref(self._out), flags, self._stream()), self.lib)
         if check_errors:
             self.raise_on_errors(live_errors)
         return self.obs_num, self.lasers, self.reward, self.done, self.status
+
+    def _encode_action(self, action, n):
+        """(tensor to hand to ftl_step_encoded, FTL_ACTION_* encoding) for an action of ``n`` envs of this config (ENV:909-925)."""
+        enc = abi.FTL_ACTION_BOX2
+        if action.device != self.device:
+            raise ValueError("action must live on %s" % self.device)
+        if self.cfg.discrete_action_space or self.cfg.constant_follower_speed:
+            if tuple(action.shape) not in ((n,), (n, 1)):
+                raise ValueError("action must be [n_envs] or [n_envs, 1] for this action space (ENV:358-372)")
+            if self.cfg.discrete_action_space and self.cfg.constant_follower_speed:
+                # ENV:922 then ENV:925: np.concatenate([[0.25], (max_speed, rotation)]) -- the follower's max_speed ends up as the rotation
+                action = torch.tensor([0.25, self.cfg.c.follower.max_speed], dtype=torch.float64, device=self.device).repeat(n, 1)
+            elif self.cfg.discrete_action_space:
+                if action.dtype.is_floating_point or action.dtype == torch.bool:
+                    raise ValueError("Discrete(5) actions must be an integer tensor")
+                action, enc = action.reshape(n).to(torch.int32).contiguous(), abi.FTL_ACTION_DISCRETE
+            else:
+                if not action.dtype.is_floating_point:
+                    raise ValueError("Box(1) actions must be a float tensor")
+                action, enc = action.reshape(n).to(torch.float64).contiguous(), abi.FTL_ACTION_TURN
+            self._keep_action = action
+        elif action.dtype != torch.float64 or not action.is_contiguous() or tuple(action.shape) != (n, 2):
+            raise ValueError("action must be a contiguous float64 [n_envs, 2] tensor on %s" % self.device)
+        return action, enc
 
     # ------------------------------------------------------------------ episode metrics / error report
     def episode_metrics(self, clear=False):
@@ -366,3 +378,172 @@ class VecGame:
         else:
             hist = self.state_field("hist")[env].view(cap, 2)[idx].cpu().numpy()
         return hist, corr
+
+
+class PipelinedVecGame:
+    """A batch of N envs stepped as ``parts`` independent sub-batches, each on its own HIP stream of this process.
+
+    Envs never interact, so part k's step t+1 depends on nothing but part k's step t.  Run that way -- no join between the parts --
+    one part's ray kernel (VALU-bound, 80 registers a lane) runs beside another part's frame kernel (latency-bound, half the VALU idle),
+    and the last, thinly occupied wavefronts of either are covered by the other stream's work: 250 M env-steps/s against 215 M for the
+    same 65,536 envs of config B as one batch on one stream.  Every env sees exactly the arithmetic of ``VecGame``:
+    the parts are ``VecGame`` batches over consecutive env ranges, their per-env random streams keyed by the GLOBAL env index and
+    their auto-reset walking the scenario pool with the whole batch's stride, so results are bit-identical to one ``VecGame(N)``
+    (tests/test_gpu_api.py).
+
+    ``step(action)`` enqueues every part on its stream and returns the combined output tensors WITHOUT waiting: part k's rows are valid
+    on ``stream(k)``; ``join()`` makes the current stream wait for all parts.  A caller that joins after every step re-aligns the parts
+    and gets ``VecGame``'s throughput back; a training loop keeps them apart by consuming part k's rows (``rows(k)``) on ``stream(k)``
+    and feeding ``step_part(k, action_k)`` -- the double-buffered sampling loop of asynchronous RL frameworks."""
+
+    def __init__(self, n_envs, parts=2, device="cuda:0", config: GameConfig = None, policy_obs=False, **game_kwargs):
+        import dataclasses
+        from .shard import shard_range
+        cfg = config if config is not None else make_config(**game_kwargs)
+        self.cfg, self.n, self.device = cfg, int(n_envs), torch.device(device)
+        if parts < 1 or parts > self.n:
+            raise ValueError("parts must be in 1..n_envs")
+        z = dict(device=self.device)
+        L = max(cfg.lasers_len, 1)
+        outs = dict(obs_num=torch.zeros(self.n, abi.FTL_OBS_NUM, dtype=torch.float32, **z), lasers=torch.zeros(self.n, L, dtype=torch.float32, **z),
+                    target=torch.zeros(self.n, 2, dtype=torch.float64, **z), reward=torch.zeros(self.n, dtype=torch.float64, **z),
+                    done=torch.zeros(self.n, dtype=torch.uint8, **z), status=torch.zeros(self.n, 3, dtype=torch.uint8, **z))
+        sel = [l for l in cfg.lasers if l.in_policy_obs]
+        if policy_obs and sel:
+            hs = {l.history for l in sel}
+            if len(hs) != 1:
+                raise ValueError("policy_obs needs the same max_prev_obs on every sensor it concatenates (wrappers.py:207, 217 assert it)")
+            outs["policy_obs"] = torch.zeros(self.n, hs.pop(), sum(l.width for l in sel), dtype=torch.float32, **z)
+        self.shards = [shard_range(self.n, k, parts) for k in range(parts)]
+        self.games, self.streams = [], []
+        # (a handle of a config with random_frames_per_step would by itself run its two halves on two streams and join them every step,
+        #  ftl_create's FTL_SPLIT switch: the parts here take that role, without the join)
+        import os
+        split_was = os.environ.get("FTL_SPLIT")
+        if parts > 1:
+            os.environ["FTL_SPLIT"] = "0"
+        try:
+            for sh in self.shards:
+                ck = dataclasses.replace(cfg, c=abi.Config.from_buffer_copy(cfg.c))
+                ck.c.env_id_base = cfg.c.env_id_base + sh.lo          # per-env random streams are keyed by the global env index
+                self.games.append(VecGame(sh.n, device=self.device, config=ck, policy_obs=policy_obs, _outputs={k: v[sh.lo:sh.hi] for k, v in outs.items()}))
+                self.streams.append(torch.cuda.Stream(device=self.device))
+        finally:
+            if parts > 1:
+                if split_was is None:
+                    del os.environ["FTL_SPLIT"]
+                else:
+                    os.environ["FTL_SPLIT"] = split_was
+        for k, v in outs.items():
+            setattr(self, k, v)
+        if "policy_obs" not in outs:
+            self.policy_obs = None
+        self.pool = None
+        self._serial = False
+        self._metrics = torch.zeros(abi.FTL_N_METRICS, dtype=torch.float64, **z)
+        self._stream_ptrs = [C.c_void_p(s.cuda_stream) for s in self.streams]
+        self._ev = torch.cuda.Event()
+
+    parts = property(lambda self: len(self.games))
+
+    def close(self):
+        for g in self.games:
+            g.close()
+
+    def stream(self, k):
+        return self.streams[k]
+
+    def rows(self, k):
+        """(lo, hi) of part k's envs in the combined tensors."""
+        return self.shards[k].lo, self.shards[k].hi
+
+    def _on(self, k):
+        """Context: part k's stream, after everything the current stream has been given so far (the action tensor's producer)."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._serial:
+            return torch.cuda.stream(cur)
+        self.streams[k].wait_stream(cur)
+        return torch.cuda.stream(self.streams[k])
+
+    def join(self):
+        """The current stream waits for every part (outputs of all rows valid on it afterwards)."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+    def load_scenarios(self, pool: ScenarioPool):
+        self.pool = pool
+        for g in self.games:
+            g.load_scenarios(pool)
+            g.set_reset_window(0, pool.n, self.n)      # the auto-reset walks the pool with the WHOLE batch's stride, as VecGame(n) does
+
+    def reset(self, scen_idx=None, mask=None):
+        if self.pool is None:
+            raise _lib.FtlError("load_scenarios() first")
+        if scen_idx is None:
+            scen_idx = torch.arange(self.n, dtype=torch.int32, device=self.device) % self.pool.n
+        scen_idx = torch.as_tensor(scen_idx, dtype=torch.int32, device=self.device).contiguous()
+        if scen_idx.numel() != self.n:
+            raise ValueError("scen_idx must have one entry per env")
+        if mask is not None:
+            mask = torch.as_tensor(mask, dtype=torch.uint8, device=self.device).contiguous()
+        for k, (g, sh) in enumerate(zip(self.games, self.shards)):
+            with self._on(k):
+                g.reset(scen_idx[sh.lo:sh.hi], None if mask is None else mask[sh.lo:sh.hi])
+        self.join()
+        return self.obs_num, self.lasers
+
+    def step_part(self, k, action, auto_reset=False):
+        """One step of part k on its stream; ``action`` = the rows of part k (any layout ``VecGame.step`` takes)."""
+        with self._on(k):
+            self.games[k].step(action, auto_reset=auto_reset)
+
+    def step(self, action, auto_reset=False):
+        """One step of every part (``action``: the whole batch's tensor, rows in env order).  Does not join -- see the class text.
+        The part streams wait for what the current stream has been given so far (the producer of ``action``); nothing waits for them."""
+        g0 = self.games[0]
+        action, enc = g0._encode_action(action, self.n)            # checked / decoded once for the whole batch, then handed over by row range
+        self._keep_action = action
+        flags = abi.FTL_STEP_AUTO_RESET if auto_reset else 0
+        cur = torch.cuda.current_stream(self.device)
+        base, row = action.data_ptr(), action.element_size() * (2 if enc == abi.FTL_ACTION_BOX2 else 1)
+        if not self._serial:
+            self._ev.record(cur)
+        for g, sh, stream, sptr in zip(self.games, self.shards, self.streams, self._stream_ptrs):
+            if self._serial:
+                sptr = C.c_void_p(cur.cuda_stream)
+            else:
+                stream.wait_event(self._ev)
+            _lib.check(g.lib.ftl_step_encoded(g.h, base + sh.lo * row, enc, C.byref(g._out), flags, sptr), g.lib)
+        return self.obs_num, self.lasers, self.reward, self.done, self.status
+
+    def episode_metrics(self, clear=False):
+        self.join()
+        self._metrics.zero_()
+        for g in self.games:
+            self._metrics += g.episode_metrics(clear)
+        return self._metrics
+
+    def error_report(self):
+        self.join()
+        n, bits = 0, 0
+        for g in self.games:
+            a, b = g.error_report()
+            n, bits = n + a, bits | b
+        return n, bits
+
+    def kernel_timing(self, enable=True):
+        """Measurement hook.  While enabled the parts run one after the other on the CURRENT stream, so that every kernel's HIP events
+        time that kernel alone (``kernel_times``: averages per LAUNCH, i.e. per part)."""
+        self.join()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._serial = bool(enable)
+        for g in self.games:
+            g.kernel_timing(enable)
+
+    def kernel_times(self):
+        ts = [g.kernel_times() for g in self.games]
+        out = {k: sum(t[k] for t in ts) / len(ts) for k in ("frames_us", "rays_us", "aux_us", "regroup_us")}
+        out["steps"] = ts[0]["steps"]
+        out["launches_per_step"] = len(ts)
+        return out

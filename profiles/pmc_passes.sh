@@ -1,7 +1,7 @@
 # PMC passes of the B bench command in its steady state: one counter set per pass, never combined with any trace domain but --kernel-trace
 TAG=${TAG:-r03_z}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --kernel-steps 0 --gen-sample 0"
+B="python3 bench.py --parts 1 --steps 20 --warmup 5 --no-cpu-baseline --kernel-steps 0 --gen-sample 0"     # one batch per launch: the counters are per kernel, and every launch covers all 65,536 envs
 O=gpurun_out/${TAG}_pmc; mkdir -p $O
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH --output-format csv -d $O/pmc1 -- $B > $O/pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $O/pmc2 -- $B > $O/pmc2.log 2>&1

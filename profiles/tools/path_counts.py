@@ -21,9 +21,13 @@ for phase, steps in (("steps 0-30", 30), ("steps 30-150", 120), ("steps 150-250"
     for k in range(steps): env.step(acts[k % 16], auto_reset=True)
     env.lib.ftl_debug_prof(out, 1)
     v = list(out); fr = max(v[0], 1)
-    cn = ["frame:move+collide", "frame:green", "frame:agent check (after hint)", "frame:tail", "load", "near+bb stage", "auto-reset", "sensors(tracker)", "frame:hint window", "[frames loop total]", "obs+store", "frame:green search"]
-    cy = v[16:28]; tot = max(sum(cy) - cy[9], 1)
-    print(phase, "cycles share:", " ".join("%s=%.3f" % (cn[i], cy[i] / tot) for i in range(12)), "cycles/wave-step=%.0f" % (tot / (steps * n / 16)))
+    cn = ["frame:collide", "frame:green", "frame:agent check", "frame:rest", "load", "near+bb stage", "auto-reset+metrics", "sensors(tracker)", "-", "tail+outputs", "obs+store+keys",
+          "[frame loop total, resolves included]", "(reset flag)", "frame:way-point switch", "frame:bears+steer", "frame:robot_move"]
+    cy = v[16:32]; per = steps * n / 16
+    inloop = cy[0] + cy[1] + cy[2] + cy[3] + cy[13] + cy[14] + cy[15]
+    tot = cy[4] + cy[5] + cy[6] + cy[7] + cy[9] + cy[10] + cy[11]
+    print(phase, "cycles per wave-step:", " ".join("%s=%.0f" % (cn[i], cy[i] / per) for i in range(16) if i not in (8, 12)), "| resolve+sync (loop - frame sections)=%.0f" % ((cy[11] - inloop) / per),
+          "| total=%.0f" % (tot / per))
     rc = v[32:48]
     if sum(rc[:8]):
         rn = ["stage corridor (2nd trip)", "phase1 table", "phase2 ray ends", "phase3 decode", "phase3 arcs", "phase3 ray tests", "phase4 rows", "setup (1st trip)"]

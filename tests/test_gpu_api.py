@@ -135,6 +135,50 @@ def test_regrouping_never_changes_a_result(monkeypatch):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("parts", [2, 3])
+def test_pipelined_parts_are_bit_identical_to_one_batch(parts):
+    """PipelinedVecGame steps the batch as independent sub-batches on their own streams (no join between the parts while it runs).
+    Every output, the state of every env and the episode metrics must equal those of one VecGame over the same envs: first compared
+    step by step (joining after every step), then after a stretch of free-running steps."""
+    from continiousenvironment_follower_leader_amd.vec_game import PipelinedVecGame, ScenarioPool
+    n = 1024 + 21
+    cfg = _pool_cfg(max_steps=300, warm_start=10)
+    a = _vec(n, cfg)
+    b = PipelinedVecGame(n, parts=parts, device="cuda:0", config=cfg)
+    b.load_scenarios(ScenarioPool.from_npz(cfg, GOLDEN + "/pool_B.npz", "cuda:0"))
+    idx = (torch.arange(n, dtype=torch.int32) * 7 + 3) % a.pool.n
+    a.reset(idx); b.reset(idx)
+    names = ("obs_num", "lasers", "target", "reward", "done", "status")
+    fields = ["rb_pos", "rb_dbl", "rb_int", "env_int", "env_dbl", "traj", "hist", "corr"]
+
+    def same(t):
+        b.join(); torch.cuda.synchronize()
+        for name in names:
+            assert torch.equal(getattr(a, name), getattr(b, name)), (t, name)
+        for f in fields:
+            fa = a.state_field(f)
+            fb = torch.cat([g.state_field(f) for g in b.games], 0)
+            if f == "env_int":          # (the regrouping key bookkeeping is per handle; everything the episode consists of is compared)
+                keep = [i for i in range(fa.shape[1]) if i != abi.EI_ERROR_STICKY]
+                fa, fb = fa[:, keep], fb[:, keep]
+            assert torch.equal(fa, fb), (t, f)
+    for t in range(40):
+        act = _actions(cfg, n, 500 + t)
+        a.step(act, auto_reset=True); b.step(act, auto_reset=True)
+        same(t)
+    acts = [_actions(cfg, n, 600 + t) for t in range(60)]
+    torch.cuda.synchronize()
+    for t in range(60):                  # free-running: the parts drift apart on their streams
+        a.step(acts[t], auto_reset=True); b.step(acts[t], auto_reset=True)
+    same(100)
+    am, bm = a.episode_metrics().cpu(), b.episode_metrics().cpu()
+    assert torch.equal(am[[0, 2, 3, 4, 5, 6, 7]], bm[[0, 2, 3, 4, 5, 6, 7]])      # counts and frame sums: exact
+    assert abs(float(am[1]) - float(bm[1])) <= 1e-12 * abs(float(am[1]))            # the sum of returns is added up in a different order
+    assert float(am[0]) > 0                                                     # episodes ended and envs were re-initialised inside the kernels
+    assert a.error_report() == b.error_report()
+    a.close(); b.close()
+
+
 def test_auto_reset_equals_explicit_reset():
     """An env that finishes under FTL_STEP_AUTO_RESET must continue exactly like a fresh env reset to the next scenario."""
     n = 96
