@@ -711,6 +711,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 const double2 e = s_ray[ray];
                 double d2;
                 if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sgx, d2)) {
+                    d2 = sqrt(d2);      // the distance itself (sensors.py:920-921); monotone, so the minimum of the roots is the root of the minimum
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
 #pragma unroll
                     for (int j = 0; j < HM; j++) if ((smx >> j) & 1u) atomicMin(&s_best[j * P.total_rays + ray], bits);
@@ -860,32 +861,60 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 }
             }
             if (any_pad) __syncthreads();
-            // one (ray, age) pair per lane, sensor by sensor (the sensor's parameters stay wave-uniform): pair q = age * N + ray
-            int rbase = 0;
-            FTL_FOR_LASERS(k) {
-                const int N = c.lasers[k].count;
-                if (c.lasers[k].after_tracker != which) { continue; }
-                const int H = c.lasers[k].history, ooff = c.lasers[k].out_offset, poff = P.pol_off[k], rb = rbase;
-                const bool pad = EXPL && c.lasers[k].pad_sectors != 0;
-                const float flen = (float)c.lasers[k].length;                       // python number / float32 array -> float32 division
-                const int Wd = pad ? 4 * N : N;
-                for (int q = lane; q < N * H; q += FTL_WAVE) {
-                    int a2 = 0;
-#pragma unroll
-                    for (int j = 1; j < HM; j++) a2 += (q >= j * N) ? 1 : 0;         // q / N without an integer division (a2 < H <= HM)
-                    const int i = q - a2 * N;
-                    int col = i;
-                    if (pad) {
-                        const double lis = (double)N / 4.0, di = (double)i;         // lasers_in_sector (sensors.py:938)
-                        col = (di < lis ? 0 : (di < 2 * lis ? 1 : (di < 3 * lis ? 2 : 3))) * N + i;
+            if constexpr (!EXPL) {
+                // One RAY per lane, the rays of all sensors of the pass in one index space (as in phase 2); the lane writes its ray's H rows
+                // (one (ray, age) pair per lane, below, takes three rounds on the bench workload and fifteen under a 180-ray sensor).
+                int n_rays = 0;
+                FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) n_rays += c.lasers[k].count;
+                for (int g = lane; g < n_rays; g += FTL_WAVE) {
+                    int i = g, H = 0, N = 0, ooff = 0, poff = -1; float flen = 1.0f; bool found = false;
+                    FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) {
+                        const int Nk = c.lasers[k].count;
+                        if (!found && i < Nk) {
+                            found = true; N = Nk; H = c.lasers[k].history; ooff = c.lasers[k].out_offset; poff = P.pol_off[k];
+                            flen = (float)c.lasers[k].length;                   // python number / float32 array -> float32 division
+                        }
+                        if (!found) i -= Nk;
                     }
-                    const unsigned long long bb = s_best[a2 * P.total_rays + rb + i];
-                    const double v = (a2 < nsnap && bb != kInfBits) ? sqrt(__longlong_as_double((long long)bb)) : s_miss[rb + i];
-                    const float vf = (float)v;
-                    out_base[ooff + (H - 1 - a2) * Wd + col] = vf;
-                    if (pol && poff >= 0) pol[(H - 1 - a2) * P.pol_width + poff + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
+                    const double miss = s_miss[g];
+#pragma unroll
+                    for (int a2 = 0; a2 < HM; a2++) if (a2 < H) {
+                        const unsigned long long bb = s_best[a2 * P.total_rays + g];
+                        const double v = (a2 < nsnap && bb != kInfBits) ? __longlong_as_double((long long)bb) : miss;
+                        const float vf = (float)v;
+                        out_base[ooff + (H - 1 - a2) * N + i] = vf;
+                        if (pol && poff >= 0) pol[(H - 1 - a2) * P.pol_width + poff + i] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
+                    }
                 }
-                rbase += N;
+            } else {
+                // the configs with the rarer sensor features (few rays per pass: a 12-ray sensor beside the compas ones): one (ray, age) pair
+                // per lane, sensor by sensor (the sensor's parameters stay wave-uniform): pair q = age * N + ray
+                int rbase = 0;
+                FTL_FOR_LASERS(k) {
+                    const int N = c.lasers[k].count;
+                    if (c.lasers[k].after_tracker != which) { continue; }
+                    const int H = c.lasers[k].history, ooff = c.lasers[k].out_offset, poff = P.pol_off[k], rb = rbase;
+                    const bool pad = c.lasers[k].pad_sectors != 0;
+                    const float flen = (float)c.lasers[k].length;                   // python number / float32 array -> float32 division
+                    const int Wd = pad ? 4 * N : N;
+                    for (int q = lane; q < N * H; q += FTL_WAVE) {
+                        int a2 = 0;
+#pragma unroll
+                        for (int j = 1; j < HM; j++) a2 += (q >= j * N) ? 1 : 0;     // q / N without an integer division (a2 < H <= HM)
+                        const int i = q - a2 * N;
+                        int col = i;
+                        if (pad) {
+                            const double lis = (double)N / 4.0, di = (double)i;     // lasers_in_sector (sensors.py:938)
+                            col = (di < lis ? 0 : (di < 2 * lis ? 1 : (di < 3 * lis ? 2 : 3))) * N + i;
+                        }
+                        const unsigned long long bb = s_best[a2 * P.total_rays + rb + i];
+                        const double v = (a2 < nsnap && bb != kInfBits) ? __longlong_as_double((long long)bb) : s_miss[rb + i];
+                        const float vf = (float)v;
+                        out_base[ooff + (H - 1 - a2) * Wd + col] = vf;
+                        if (pol && poff >= 0) pol[(H - 1 - a2) * P.pol_width + poff + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
+                    }
+                    rbase += N;
+                }
             }
         }
         FTL_RTIC(6);
