@@ -66,6 +66,7 @@ def load():
     lib.ftl_state_field.argtypes = [vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(i32), C.POINTER(C.c_size_t)]
     lib.ftl_load_scenarios.argtypes = [vp, C.POINTER(abi.Scenarios)]
     lib.ftl_set_reset_window.argtypes = [vp, i32, i32, i32]
+    lib.ftl_tune.argtypes = [vp, i32, i32]
     lib.ftl_reset.argtypes = [vp, vp, vp, C.POINTER(abi.Outputs), vp]
     lib.ftl_step.argtypes = [vp, vp, C.POINTER(abi.Outputs), u32, vp]
     lib.ftl_step_encoded.argtypes = [vp, vp, i32, C.POINTER(abi.Outputs), u32, vp]
@@ -96,7 +97,7 @@ def load():
 
 
 EXPORTS = ("ftl_create", "ftl_destroy", "ftl_lasers_len", "ftl_get_config", "ftl_state_bytes", "ftl_bind_state",
-           "ftl_state_field", "ftl_load_scenarios", "ftl_set_reset_window", "ftl_reset", "ftl_step", "ftl_step_encoded", "ftl_last_error", "ftl_generate_scenarios",
+           "ftl_state_field", "ftl_load_scenarios", "ftl_set_reset_window", "ftl_tune", "ftl_reset", "ftl_step", "ftl_step_encoded", "ftl_last_error", "ftl_generate_scenarios",
            "ftl_episode_metrics", "ftl_kernel_timing", "ftl_kernel_times",
            "ftl_gz_create", "ftl_gz_destroy", "ftl_gz_state_bytes", "ftl_gz_bind_state", "ftl_gz_lasers_len", "ftl_gz_reset", "ftl_gz_step",
            "ftl_gz_state_field")

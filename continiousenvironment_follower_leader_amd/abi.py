@@ -148,3 +148,6 @@ SCEN_FOUND, SCEN_DONE_AT_RESET, SCEN_ROUTE_OVERFLOW, SCEN_TRAJ_OVERFLOW, SCEN_RE
 class Outputs(C.Structure):
     _fields_ = [("obs_num", C.c_void_p), ("lasers", C.c_void_p), ("target", C.c_void_p),
                 ("reward", C.c_void_p), ("done", C.c_void_p), ("status", C.c_void_p), ("policy_obs", C.c_void_p)]
+
+# ftl_tune keys (include/ftl.h)
+FTL_TUNE_COSCHEDULED_ENVS, FTL_TUNE_REGROUP_EVERY, FTL_TUNE_TWO_STREAMS = 0, 1, 2

@@ -42,6 +42,8 @@ struct ftl_handle {
     void* rg_mem;            // perm | bh | rank | keys | two key-total buffers (library-owned)
     int* rg_tot;             // [2][FTL_NKEYS]
     unsigned rg_parity, rg_launches, rg_every;
+    bool rg_env, rg_every_env, split_env;   // the environment switch was given: it wins over ftl_tune
+    int rg_slots, rg_epw;    // frame-kernel wavefronts one round holds on this device / envs per wavefront (the cost sort's auto rule)
     // optionally the slot groups are stepped as two interleaved halves on two streams (the caller's stream waits for the side
     // stream): the ray kernel of one half fills the tail of the other half's frame kernel
     hipStream_t side; hipEvent_t ev_fork, ev_join; bool split;
@@ -132,6 +134,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         // fixed 10 frames per step -- so it is on for the former only; FTL_SPLIT=0/1 overrides
         const char* sp = getenv("FTL_SPLIT");
         h->split = n_envs >= 8192 && (sp ? sp[0] == '1' : cfg->rand_fps_hi > 0) && cfg->has_tracker != 1;   // (the v1 tracker kernel covers all envs at once)
+        h->split_env = sp != nullptr;
     }
     {   // the scatter pass reads one histogram row per block of 1024 envs: fine up to a few hundred blocks
         const char* off = getenv("FTL_NO_REGROUP");
@@ -148,6 +151,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         const int epw_f = FTL_WAVE / (2 + cfg->n_bears <= 4 ? 4 : 8);
         const bool beyond_one_round = (n_envs + epw_f - 1) / epw_f > cus * 4 * FTL_FRAMESG_WPE;
         h->regroup = (off ? off[0] != '1' : (beyond_one_round || cfg->rand_fps_hi > 0)) && (n_envs + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK <= 512;
+        h->rg_env = off != nullptr; h->rg_every_env = ev && atoi(ev) > 0; h->rg_slots = cus * 4 * FTL_FRAMESG_WPE; h->rg_epw = epw_f;
     }
     FtlDevParams& P = h->P;
     P.n_envs = n_envs;
@@ -350,6 +354,25 @@ int ftl_set_reset_window(ftl_handle* h, int32_t base, int32_t count, int32_t str
     if (base < 0 || count <= 0 || base + count > h->P.scen.n_scenarios) return fail(FTL_E_INVALID, "reset window outside the scenario pool");
     h->win_base = base; h->win_count = count; h->win_stride = (stride > 0 ? stride : h->P.n_envs) % count;
     return FTL_OK;
+}
+
+int ftl_tune(ftl_handle* h, int32_t what, int32_t value) {
+    if (!h) return fail(FTL_E_INVALID, "null argument");
+    switch (what) {
+    case FTL_TUNE_COSCHEDULED_ENVS:
+        if (value < h->P.n_envs) return fail(FTL_E_INVALID, "co-scheduled envs below this handle's own");
+        if (!h->rg_env)
+            h->regroup = ((value + h->rg_epw - 1) / h->rg_epw > h->rg_slots || h->P.cfg.rand_fps_hi > 0) && (h->P.n_envs + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK <= 512;
+        return FTL_OK;
+    case FTL_TUNE_REGROUP_EVERY:
+        if (value < 1) return fail(FTL_E_INVALID, "regroup interval below 1");
+        if (!h->rg_every_env) h->rg_every = (unsigned)value;
+        return FTL_OK;
+    case FTL_TUNE_TWO_STREAMS:
+        if (!h->split_env) h->split = value != 0 && h->P.n_envs >= 8192 && h->P.cfg.has_tracker != 1;
+        return FTL_OK;
+    }
+    return fail(FTL_E_INVALID, "unknown tuning key");
 }
 
 // device copy of the frozen parameters: (re)uploaded only after bind_state / load_scenarios, never on the steady-state step path

@@ -216,6 +216,13 @@ class VecGame:
         batch.  ``stride`` should be coprime to ``count`` (0 keeps n_envs)."""
         _lib.check(self.lib.ftl_set_reset_window(self.h, int(base), int(count), int(stride)), self.lib)
 
+    def tune(self, coscheduled_envs=None, regroup_every=None, two_streams=None):
+        """Scheduling hints (``ftl_tune``; results never depend on them): how many envs are stepped on the device at the same time when
+        this batch is one of several on several streams, how often the cost order of the envs is rebuilt, the handle's own two-stream mode."""
+        for key, v in ((abi.FTL_TUNE_COSCHEDULED_ENVS, coscheduled_envs), (abi.FTL_TUNE_REGROUP_EVERY, regroup_every), (abi.FTL_TUNE_TWO_STREAMS, two_streams)):
+            if v is not None:
+                _lib.check(self.lib.ftl_tune(self.h, key, int(v)), self.lib)
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -416,24 +423,16 @@ class PipelinedVecGame:
             outs["policy_obs"] = torch.zeros(self.n, hs.pop(), sum(l.width for l in sel), dtype=torch.float32, **z)
         self.shards = [shard_range(self.n, k, parts) for k in range(parts)]
         self.games, self.streams = [], []
-        # (a handle of a config with random_frames_per_step would by itself run its two halves on two streams and join them every step,
-        #  ftl_create's FTL_SPLIT switch: the parts here take that role, without the join)
-        import os
-        split_was = os.environ.get("FTL_SPLIT")
-        if parts > 1:
-            os.environ["FTL_SPLIT"] = "0"
-        try:
-            for sh in self.shards:
-                ck = dataclasses.replace(cfg, c=abi.Config.from_buffer_copy(cfg.c))
-                ck.c.env_id_base = cfg.c.env_id_base + sh.lo          # per-env random streams are keyed by the global env index
-                self.games.append(VecGame(sh.n, device=self.device, config=ck, policy_obs=policy_obs, _outputs={k: v[sh.lo:sh.hi] for k, v in outs.items()}))
-                self.streams.append(torch.cuda.Stream(device=self.device))
-        finally:
+        for sh in self.shards:
+            ck = dataclasses.replace(cfg, c=abi.Config.from_buffer_copy(cfg.c))
+            ck.c.env_id_base = cfg.c.env_id_base + sh.lo          # per-env random streams are keyed by the global env index
+            g = VecGame(sh.n, device=self.device, config=ck, policy_obs=policy_obs, _outputs={k: v[sh.lo:sh.hi] for k, v in outs.items()})
             if parts > 1:
-                if split_was is None:
-                    del os.environ["FTL_SPLIT"]
-                else:
-                    os.environ["FTL_SPLIT"] = split_was
+                # the parts take the role of the handle's own two-stream mode (random_frames_per_step), without its join; the envs are sorted
+                # by cost when the WHOLE batch oversubscribes the device, on a staler order than a lone handle's (259 against 255 M env-steps/s)
+                g.tune(two_streams=0, coscheduled_envs=self.n, regroup_every=8)
+            self.games.append(g)
+            self.streams.append(torch.cuda.Stream(device=self.device))
         for k, v in outs.items():
             setattr(self, k, v)
         if "policy_obs" not in outs:

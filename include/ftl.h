@@ -320,6 +320,18 @@ int ftl_load_scenarios(ftl_handle* h, const ftl_scenarios* pool);
  * started before the window left it has ended (at most max_steps / frames_per_step + 1 steps). */
 int ftl_set_reset_window(ftl_handle* h, int32_t base, int32_t count, int32_t stride);
 
+/* Scheduling hints of a handle.  Results never depend on them (tests/test_gpu_api.py: regrouping, split path, pipelined parts).
+ * FTL_TUNE_COSCHEDULED_ENVS: the number of envs that are stepped on this device at the same time, this handle's included -- a caller that
+ *   runs the batch as several handles on several streams (two handles of 32,768 envs each: DESIGN.md section 6, PipelinedVecGame) says
+ *   65,536 here.  The handle sorts its envs by expected cost when THAT many envs need more than one round of frame-kernel wavefronts
+ *   (by itself it only knows its own batch, which it leaves unsorted when one round holds it).
+ * FTL_TUNE_REGROUP_EVERY: rebuild the cost order every k-th step (default 4).
+ * FTL_TUNE_TWO_STREAMS: 0 / 1 -- the handle's own two-stream mode (its two halves on two streams, joined every step: the default for
+ *   configs with random_frames_per_step); a caller that overlaps whole handles switches it off.
+ * The environment switches FTL_NO_REGROUP / FTL_REGROUP_EVERY / FTL_SPLIT (diagnostics) win over the hints. */
+enum { FTL_TUNE_COSCHEDULED_ENVS = 0, FTL_TUNE_REGROUP_EVERY = 1, FTL_TUNE_TWO_STREAMS = 2 };
+int ftl_tune(ftl_handle* h, int32_t what, int32_t value);
+
 /* reset() (ENV:494-543): place env e at scenario scen_idx[e] for every e with mask[e] != 0 (mask NULL = all),
  * run the initial use_sensors (ENV:541) and write the first observation.  reward/done/status are zeroed. */
 int ftl_reset(ftl_handle* h, const int32_t* scen_idx, const uint8_t* mask, const ftl_outputs* out, void* stream);

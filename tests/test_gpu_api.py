@@ -135,8 +135,21 @@ def test_regrouping_never_changes_a_result(monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("parts", [2, 3])
-def test_pipelined_parts_are_bit_identical_to_one_batch(parts):
+def test_tune_hints_are_accepted_and_checked():
+    from continiousenvironment_follower_leader_amd import _lib
+    g = _vec(256, _pool_cfg())
+    g.tune(coscheduled_envs=65536, regroup_every=8, two_streams=0)
+    with pytest.raises(ValueError):
+        g.tune(coscheduled_envs=100)              # fewer than the handle's own envs
+    with pytest.raises(ValueError):
+        g.tune(regroup_every=0)
+    with pytest.raises(ValueError):
+        _lib.check(g.lib.ftl_tune(g.h, 99, 1), g.lib)
+    g.close()
+
+
+@pytest.mark.parametrize("parts,sorted_envs", [(2, False), (3, False), (2, True)])
+def test_pipelined_parts_are_bit_identical_to_one_batch(parts, sorted_envs, monkeypatch):
     """PipelinedVecGame steps the batch as independent sub-batches on their own streams (no join between the parts while it runs).
     Every output, the state of every env and the episode metrics must equal those of one VecGame over the same envs: first compared
     step by step (joining after every step), then after a stretch of free-running steps."""
@@ -144,7 +157,11 @@ def test_pipelined_parts_are_bit_identical_to_one_batch(parts):
     n = 1024 + 21
     cfg = _pool_cfg(max_steps=300, warm_start=10)
     a = _vec(n, cfg)
+    if sorted_envs:          # the parts keep their envs sorted by cost (what the co-scheduling hint switches on at the full batch size)
+        monkeypatch.setenv("FTL_NO_REGROUP", "0")
     b = PipelinedVecGame(n, parts=parts, device="cuda:0", config=cfg)
+    if sorted_envs:
+        monkeypatch.delenv("FTL_NO_REGROUP")
     b.load_scenarios(ScenarioPool.from_npz(cfg, GOLDEN + "/pool_B.npz", "cuda:0"))
     idx = (torch.arange(n, dtype=torch.int32) * 7 + 3) % a.pool.n
     a.reset(idx); b.reset(idx)
