@@ -222,8 +222,6 @@ def main():
     n = sh.n
     cfg, pool, workload_text, bpe, knames = build_workload(a.workload, sh.lo, a.seed, device)
     parts = a.parts if a.parts > 0 else DEFAULT_PARTS
-    if a.ring > 0:                                 # (the ring moves ONE handle's reset window)
-        parts = 1
     parts = max(1, min(parts, n))
     if parts > 1:
         from continiousenvironment_follower_leader_amd.vec_game import PipelinedVecGame

@@ -192,6 +192,8 @@ class ScenarioRing:
                 # `step` counts the steps the HOST has queued; the device may be many steps behind.  The copy must not overtake them:
                 # the side stream waits for everything queued on the batch's stream so far (steps that may still read this half).
                 self._stream.wait_stream(torch.cuda.current_stream(self.device))
+                for st in getattr(env, "streams", ()):           # (a PipelinedVecGame steps its parts on streams of their own)
+                    self._stream.wait_stream(st)
                 self.pool.write(other * self.half, host, self._stream)
                 ev = torch.cuda.Event()
                 ev.record(self._stream)

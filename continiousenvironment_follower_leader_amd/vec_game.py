@@ -476,6 +476,16 @@ class PipelinedVecGame:
             g.load_scenarios(pool)
             g.set_reset_window(0, pool.n, self.n)      # the auto-reset walks the pool with the WHOLE batch's stride, as VecGame(n) does
 
+    def set_reset_window(self, base, count, stride=0):
+        """``VecGame.set_reset_window`` for every part; ``stride`` 0 keeps the whole batch's n_envs."""
+        for g in self.games:
+            g.set_reset_window(base, count, stride if stride > 0 else self.n)
+
+    def state_field(self, name):
+        """[n_envs, per_env] COPY of a named state field over all parts (``VecGame.state_field`` gives views, part by part)."""
+        self.join()
+        return torch.cat([g.state_field(name) for g in self.games], 0)
+
     def reset(self, scen_idx=None, mask=None):
         if self.pool is None:
             raise _lib.FtlError("load_scenarios() first")

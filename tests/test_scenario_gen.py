@@ -118,7 +118,7 @@ def test_generator_route_properties_and_threads():
 @pytest.mark.gpu
 def test_generated_pool_runs_on_device():
     import torch
-    from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
+    from continiousenvironment_follower_leader_amd.vec_game import PipelinedVecGame, ScenarioPool, VecGame
     z = np.load(GOLDEN + "/pool_B.npz")
     meta = json.loads(str(z["meta"]))
     cfg = config_for(dict(kwargs=meta["kwargs"], post=None), scen_route_len=256)
@@ -140,7 +140,8 @@ def test_generated_pool_runs_on_device():
 
 
 @pytest.mark.gpu
-def test_scenario_ring_refills_while_stepping():
+@pytest.mark.parametrize("parts", [1, 2])
+def test_scenario_ring_refills_while_stepping(parts):
     """ScenarioRing (row f2 at the step rate): generator threads build the next half of the pool while the batch steps, an asynchronous copy
     fills the half no running episode can still read, the reset window moves at a step boundary.  A second run that writes the SAME halves
     synchronously at the SAME steps must produce identical outputs at every step: the background generation, the side-stream copy and the
@@ -148,7 +149,7 @@ def test_scenario_ring_refills_while_stepping():
     import time
     import torch
     from continiousenvironment_follower_leader_amd.scenario import ScenarioRing
-    from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
+    from continiousenvironment_follower_leader_amd.vec_game import PipelinedVecGame, ScenarioPool, VecGame
     z = np.load(GOLDEN + "/pool_B.npz")
     meta = json.loads(str(z["meta"]))
     cfg = config_for(dict(kwargs=dict(meta["kwargs"], max_steps=120, warm_start=10), post=None), scen_route_len=256)
@@ -160,7 +161,8 @@ def test_scenario_ring_refills_while_stepping():
 
     ring = ScenarioRing(cfg, half, "cuda:0", iter(range(20000, 10 ** 9)), n_threads=4, record=True)
     assert ring.horizon == 120 // 10 + 2
-    a = VecGame(n, device="cuda:0", config=cfg)
+    # (parts = 2: the batch as two sub-batches on their own streams -- the copy into a half must wait for both)
+    a = VecGame(n, device="cuda:0", config=cfg) if parts == 1 else PipelinedVecGame(n, parts=parts, device="cuda:0", config=cfg)
     ring.attach(a)
     idx = (torch.arange(n) % half).to(torch.int32)
     a.reset(idx)
@@ -168,6 +170,8 @@ def test_scenario_ring_refills_while_stepping():
     for t in range(T):
         ring.poll(a, t)
         a.step(acts[t], auto_reset=True)
+        if parts > 1:
+            a.join()
         outs.append((a.obs_num.clone(), a.lasers.clone(), a.reward.clone(), a.done.clone(), a.status.clone()))
         if t % 10 == 9:
             torch.cuda.synchronize(); time.sleep(0.05)      # give the generator threads time: several window moves inside the run
