@@ -347,11 +347,13 @@ def main():
         if ktimes:
             # the dominant kernel of the step
             dom = max(("frames", "rays", "aux"), key=lambda k: ktimes[k + "_us"])
-        # One step = the launches of one ftl_step on one stream: the frame kernel, the ray kernel (+ ftl_aux_kernel, + the regroup kernels every
-        # 2nd step).  SURVEY 8(d)'s algorithmic bytes per env-step cover the whole step, so the roofline figure is bytes of one step / duration of
-        # one step, the duration from the HIP events around the timed region on the launch stream (step_ms_events).  kernels_us splits it per
-        # kernel from a separate pass with an event after every launch (each such event adds ~4.5 us of its own, which is why the parts exceed
-        # the whole: diagnostics, not the denominator).
+        # One step = every env advanced once: the launches of one ftl_step per part -- the frame kernel, the ray kernel (+ ftl_aux_kernel, + the
+        # regroup kernels every k-th step) -- on the part's stream.  SURVEY 8(d)'s algorithmic bytes per env-step cover the whole step, so the
+        # roofline figure is bytes of one step / duration of one step, the duration from the HIP events that bracket the timed region on the
+        # launch stream (the part streams start after the first event and are joined before the second: step_ms_events).  With more than one
+        # part the launches of different streams overlap, so no kernel has a share of the step of its own; kernels_us gives what each LAUNCH
+        # takes alone, from a separate pass that runs the parts one after the other with an event after every launch (diagnostics, not the
+        # denominator; each such event adds ~4.5 us of its own).
         kernel_ms = step_ms
         launch_bytes = bpe * n
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
@@ -364,9 +366,9 @@ def main():
                 prof = {}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": prof.get("hbm_bytes_per_step"), "traffic_source": prof.get("source"),
-                "kernel": "%s + %s (one step = both launches on one stream + the regroup kernels every 2nd step; achieved = algorithmic bytes of a "
-                          "step / step duration from HIP events over the timed region; HBM is the contract roofline, the ray kernel is VALU-issue "
-                          "bound and the frame kernel latency bound -- see valu)" % knames,
+                "kernel": "%s + %s (one step = both launches for every one of the %d part(s) + the regroup kernels every 4th / 8th step; achieved = "
+                          "algorithmic bytes of a step / step duration from HIP events over the timed region; HBM is the contract roofline, the ray "
+                          "kernel is VALU-issue bound and the frame kernel latency bound -- see valu)" % (knames[0], knames[1], parts),
                 "kernel_ms": kernel_ms, "step_ms_events": step_ms, "bytes_per_env_step": bpe,
                 "kernels_us": ktimes, "kernels_us_from": kmode if ktimes else None, "valu": prof.get("valu")}
         if ktimes:
