@@ -9,7 +9,7 @@ python3 bench.py > gpurun_out/${TAG}_bench.log 2>&1 && tail -1 gpurun_out/${TAG}
 python3 bench.py --parts 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_B_1part.log 2>&1 && tail -1 gpurun_out/${TAG}_bench_B_1part.log > gpurun_out/${TAG}_bench_B_1part.json   # one batch on one stream
 for n in 4096 8192 16384 32768; do python3 bench.py --total-envs $n --steps 200 --no-cpu-baseline > gpurun_out/${TAG}_bench_B$n.log 2>&1 && tail -1 gpurun_out/${TAG}_bench_B$n.log > gpurun_out/${TAG}_bench_B$((n/1024))k.json; done
 for w in D E F C L T; do python3 bench.py --workload $w --steps 200 > gpurun_out/${TAG}_bench_$w.log 2>&1 && tail -1 gpurun_out/${TAG}_bench_$w.log > gpurun_out/${TAG}_bench_$w.json; done
-python3 bench.py --steps 1500 --no-cpu-baseline --ring 16384 > gpurun_out/${TAG}_bench_ring.log 2>&1 && tail -1 gpurun_out/${TAG}_bench_ring.log > gpurun_out/${TAG}_bench_ring.json
+python3 bench.py --steps 6000 --no-cpu-baseline --kernel-steps 0 --gen-sample 0 --ring 16384 > gpurun_out/${TAG}_bench_ring.log 2>&1 && tail -1 gpurun_out/${TAG}_bench_ring.log > gpurun_out/${TAG}_bench_ring.json
 fi
 if [[ $PART == *b* ]]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- python3 bench.py --no-cpu-baseline --kernel-steps 0 --gen-sample 0 > gpurun_out/${TAG}_stats.log 2>&1
