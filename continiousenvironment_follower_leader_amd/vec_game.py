@@ -541,6 +541,24 @@ class PipelinedVecGame:
             n, bits = n + a, bits | b
         return n, bits
 
+    def raise_on_errors(self, live=False):
+        """``VecGame.raise_on_errors`` over all parts (joins first)."""
+        self.join()
+        for g in self.games:
+            g.raise_on_errors(live)
+
+    def laser_view(self, name):
+        for l in self.cfg.lasers:
+            if l.name == name:
+                return self.lasers[:, l.out_offset:l.out_offset + l.history * l.width].view(self.n, l.history, l.width)
+        raise KeyError(name)
+
+    def aux_view(self, name):
+        for a in self.cfg.aux:
+            if a.name == name:
+                return self.lasers[:, a.out_offset:a.out_offset + a.out_len].view(self.n, *a.shape)
+        raise KeyError(name)
+
     def kernel_timing(self, enable=True):
         """Measurement hook.  While enabled the parts run one after the other on the CURRENT stream, so that every kernel's HIP events
         time that kernel alone (``kernel_times``: averages per LAUNCH, i.e. per part)."""

@@ -188,6 +188,17 @@ def test_pipelined_parts_are_bit_identical_to_one_batch(parts, sorted_envs, monk
     for t in range(60):                  # free-running: the parts drift apart on their streams
         a.step(acts[t], auto_reset=True); b.step(acts[t], auto_reset=True)
     same(100)
+    # the double-buffered form: every part is stepped on its own, several steps ahead of the next one
+    acts = [_actions(cfg, n, 700 + t) for t in range(12)]
+    torch.cuda.synchronize()
+    for t in range(12):
+        a.step(acts[t], auto_reset=True)
+    for k in range(b.parts):
+        lo, hi = b.rows(k)
+        for t in range(12):
+            b.step_part(k, acts[t][lo:hi].contiguous(), auto_reset=True)
+    same(200)
+    assert torch.equal(a.laser_view(cfg.lasers[0].name), b.laser_view(cfg.lasers[0].name))
     am, bm = a.episode_metrics().cpu(), b.episode_metrics().cpu()
     assert torch.equal(am[[0, 2, 3, 4, 5, 6, 7]], bm[[0, 2, 3, 4, 5, 6, 7]])      # counts and frame sums: exact
     assert abs(float(am[1]) - float(bm[1])) <= 1e-12 * abs(float(am[1]))            # the sum of returns is added up in a different order
