@@ -506,6 +506,8 @@ class PipelinedVecGame:
         """One step of part k on its stream; ``action`` = the rows of part k (any layout ``VecGame.step`` takes)."""
         with self._on(k):
             self.games[k].step(action, auto_reset=auto_reset)
+            if not self._serial:
+                action.record_stream(self.streams[k])
 
     def step(self, action, auto_reset=False):
         """One step of every part (``action``: the whole batch's tensor, rows in env order).  Does not join -- see the class text.
@@ -523,6 +525,7 @@ class PipelinedVecGame:
                 sptr = C.c_void_p(cur.cuda_stream)
             else:
                 stream.wait_event(self._ev)
+                action.record_stream(stream)       # (the caller may drop the tensor right away: its memory must outlive the part's read)
             _lib.check(g.lib.ftl_step_encoded(g.h, base + sh.lo * row, enc, C.byref(g._out), flags, sptr), g.lib)
         return self.obs_num, self.lasers, self.reward, self.done, self.status
 
