@@ -254,7 +254,7 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         P.corr_lds_cap = cfg->corr_cap < 128 ? cfg->corr_cap : 128;
         if (const char* lc = getenv("FTL_DEBUG_CORR_LDS_CAP")) { int v = atoi(lc); if (v >= 2 && v <= cfg->corr_cap && (v & (v - 1)) == 0) P.corr_lds_cap = v; }
         P.lds_rays = (int)((size_t)P.corr_lds_cap * 16 + rects * 20 + (size_t)2 * P.corr_lds_cap * 4 + (size_t)2 * hmax * 20 + 64
-                           + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : FTL_HMAX) * 8      /* >= the HM of whichever instantiation launch() picks */ + (size_t)rays * 8
+                           + (size_t)rays * 16 + (size_t)rays * (hmax <= 5 ? 5 : FTL_HMAX) * 4      /* float32 minima, >= the HM of whichever instantiation launch() picks */ + (size_t)rays * 4
                            + rects * 8 + 32                   /* facing-edge list (u16 x 4 per rect) + edge counters */
                            + (size_t)FTL_PAIR_CAP * 2 + 16);  /* candidate list of phase 3 */
     }

@@ -479,10 +479,13 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
     unsigned short* s_edge = reinterpret_cast<unsigned short*>(s_cnt + 8);       // [4 * (cap_rs + cap_rd)]: rect slot << 2 | edge, the edges facing the follower
     const int n_u32 = (cap_rs + cap_rd) + cap_cr + cap_gr + 8 + 2 * (cap_rs + cap_rd);   // words since the last 16-byte aligned array
     double2* s_ray = reinterpret_cast<double2*>(s_rmask + ((n_u32 + 3) & ~3));     // 16-byte aligned [total_rays]
-    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_ray + P.total_rays);          // [HM][total_rays]
-    double* s_miss = reinterpret_cast<double*>(s_best + (size_t)P.total_rays * HM);                     // [total_rays] |ray end - origin|
+    // The minima are kept as the float32 the output array holds (sensors.py:896-901: float32(min of the float64 distances) -- rounding is
+    // monotone, so the minimum of the rounded values is the rounded minimum; non-negative floats order like their bit patterns).  Half
+    // the LDS of float64 minima: with the frame kernel of another stream on the same CU, LDS is what limits how many of these wavefronts fit.
+    unsigned* s_best = reinterpret_cast<unsigned*>(s_ray + P.total_rays);                                // [HM][total_rays]
+    float* s_miss = reinterpret_cast<float*>(s_best + (size_t)P.total_rays * HM);                        // [total_rays] float32(|ray end - origin|)
     unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_miss + P.total_rays);                  // [FTL_PAIR_CAP] candidate list of phase 3
-    const unsigned long long kInfBits = 0x7fefffffffffffffull;                                       // DBL_MAX: "no hit"
+    const unsigned kInfBits = 0x7f800000u;                                                            // +inf: "no hit"
 
     // Round trip 1: everything that is addressed by the env index alone is requested at once -- the scalars, every ring slot
     // of the snapshot windows (one word per lane) and of the snapshot rects (one rect per lane); which slots are valid is
@@ -656,8 +659,8 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 const double co = fcd * rot.x - fsd * rot.y, s = fsd * rot.x + fcd * rot.y;
                 const double ex = (double)cx + co * len, ey = (double)cy + s * len;
                 s_ray[g] = make_double2(ex, ey);
-                if (P.miss_const) s_miss[g] = (double)(float)len;                    // np.linalg.norm(end - position), sensors.py:925-930
-                else { const double qx0 = ex - (double)cx, qy0 = ey - (double)cy; s_miss[g] = sqrt(__builtin_fma(qy0, qy0, qx0 * qx0)); }
+                if (P.miss_const) s_miss[g] = (float)len;                            // np.linalg.norm(end - position), sensors.py:925-930
+                else { const double qx0 = ex - (double)cx, qy0 = ey - (double)cy; s_miss[g] = (float)sqrt(__builtin_fma(qy0, qy0, qx0 * qx0)); }
 #pragma unroll
                 for (int j = 0; j < HM; j++) s_best[j * P.total_rays + g] = kInfBits;       // [age][ray]: the lanes of a row read / write consecutive words
             }
@@ -712,7 +715,7 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                 double d2;
                 if (hit_segment(cx, cy, e.x, e.y, (float)e.x, (float)e.y, sgx, d2)) {
                     d2 = sqrt(d2);      // the distance itself (sensors.py:920-921); monotone, so the minimum of the roots is the root of the minimum
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
+                    const unsigned bits = __float_as_uint((float)d2);
 #pragma unroll
                     for (int j = 0; j < HM; j++) if ((smx >> j) & 1u) atomicMin(&s_best[j * P.total_rays + ray], bits);
                 }
@@ -876,12 +879,11 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                         }
                         if (!found) i -= Nk;
                     }
-                    const double miss = s_miss[g];
+                    const float miss = s_miss[g];
 #pragma unroll
                     for (int a2 = 0; a2 < HM; a2++) if (a2 < H) {
-                        const unsigned long long bb = s_best[a2 * P.total_rays + g];
-                        const double v = (a2 < nsnap && bb != kInfBits) ? __longlong_as_double((long long)bb) : miss;
-                        const float vf = (float)v;
+                        const unsigned bb = s_best[a2 * P.total_rays + g];
+                        const float vf = (a2 < nsnap && bb != kInfBits) ? __uint_as_float(bb) : miss;
                         out_base[ooff + (H - 1 - a2) * N + i] = vf;
                         if (pol && poff >= 0) pol[(H - 1 - a2) * P.pol_width + poff + i] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
                     }
@@ -907,9 +909,8 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
                             const double lis = (double)N / 4.0, di = (double)i;     // lasers_in_sector (sensors.py:938)
                             col = (di < lis ? 0 : (di < 2 * lis ? 1 : (di < 3 * lis ? 2 : 3))) * N + i;
                         }
-                        const unsigned long long bb = s_best[a2 * P.total_rays + rb + i];
-                        const double v = (a2 < nsnap && bb != kInfBits) ? __longlong_as_double((long long)bb) : s_miss[rb + i];
-                        const float vf = (float)v;
+                        const unsigned bb = s_best[a2 * P.total_rays + rb + i];
+                        const float vf = (a2 < nsnap && bb != kInfBits) ? __uint_as_float(bb) : s_miss[rb + i];
                         out_base[ooff + (H - 1 - a2) * Wd + col] = vf;
                         if (pol && poff >= 0) pol[(H - 1 - a2) * P.pol_width + poff + col] = fminf(fmaxf(vf / flen, 0.0f), 1.0f);
                     }
