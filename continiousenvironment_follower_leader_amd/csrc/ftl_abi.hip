@@ -43,6 +43,9 @@ struct ftl_handle {
     int* rg_tot;             // [2][FTL_NKEYS]
     unsigned rg_parity, rg_launches, rg_every;
     bool rg_env, rg_every_env, split_env;   // the environment switch was given: it wins over ftl_tune
+    int G;                   // lanes per env in the frame kernel (set_lanes)
+    int co_envs, cus;        // envs stepped on the device at the same time (ftl_tune; default: this handle's), CUs of the device
+    bool g_env;              // FTL_DEBUG_G8 was given
     int rg_slots, rg_epw;    // frame-kernel wavefronts one round holds on this device / envs per wavefront (the cost sort's auto rule)
     // optionally the slot groups are stepped as two interleaved halves on two streams (the caller's stream waits for the side
     // stream): the ray kernel of one half fills the tail of the other half's frame kernel
@@ -115,6 +118,29 @@ size_t ftl_sizeof_scenarios(void) { return sizeof(ftl_scenarios); }
 size_t ftl_sizeof_outputs(void) { return sizeof(ftl_outputs); }
 size_t ftl_sizeof_scen_params(void) { return sizeof(ftl_scen_params); }
 
+// Lanes per env of the frame kernel (4 or 8) and everything that follows from the envs per wavefront: the LDS layout of the kernel and the
+// slot count of the cost sort's rule.  Configs with more than 2 dynamic obstacles need 8 lanes.  The others take 8 as well -- 8 envs per
+// wavefront, five lanes of a group idle -- when the batch is small enough for every such wavefront to have a SIMD of its own: the launch
+// then takes as long as its slowest wavefront, and a wavefront with half the envs meets half the rare paths (resets, searches, walks):
+// config B at 8,192 envs +3 %, config D +4 %, nothing from 16,384 envs on.  FTL_DEBUG_G8=0/1 overrides.  0 on success.
+static int set_lanes(ftl_handle* h) {
+    FtlDevParams& P = h->P;
+    const ftl_config* cfg = &P.cfg;
+    if (!h->g_env) h->G = (P.R > 4 || h->co_envs <= h->cus * 4 * 8) ? 8 : 4;
+    if (P.R > 4) h->G = 8;
+    const int epw = FTL_WAVE / h->G;
+    h->rg_epw = epw;
+    const int f_max = cfg->rand_fps_hi > 0 ? cfg->rand_fps_hi - 1 : cfg->frames_per_step;
+    size_t o = align_up((size_t)epw * cfg->n_static * 16 + (size_t)epw * 4 + 32, 16);
+    P.fr_rec_stride = (int)align_up((size_t)f_max, 16);
+    P.fr_rec_off = (int)o; o += (size_t)P.fr_rec_stride * epw;
+    P.fr_pend_off = (int)o; o += (size_t)epw * (P.fr_defer ? f_max - 1 : 1) * 16;
+    P.fr_env_off = (int)o; o += (size_t)epw * 4 + 16 + (size_t)epw * 16;      // slot -> env, item counter, box of the trajectory block being filled
+    P.fr_lds = (int)o;
+    h->dirty = true;
+    return o > 64 * 1024 ? 1 : 0;
+}
+
 int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle** out) {
     if (!cfg || !out) return fail(FTL_E_INVALID, "null argument");
     if (n_envs <= 0) return fail(FTL_E_INVALID, "n_envs must be positive");
@@ -148,7 +174,10 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
         // beyond one round -- or with random frame counts, whose keys make the wavefronts uniform in length.  FTL_NO_REGROUP=0/1 overrides.
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        const int epw_f = FTL_WAVE / (2 + cfg->n_bears <= 4 ? 4 : 8);
+        const char* g8 = getenv("FTL_DEBUG_G8");
+        h->g_env = g8 != nullptr; h->cus = cus; h->co_envs = n_envs;
+        h->G = (2 + cfg->n_bears > 4 || (g8 ? g8[0] == '1' : n_envs <= cus * 4 * 8)) ? 8 : 4;       // (set_lanes)
+        const int epw_f = FTL_WAVE / h->G;
         const bool beyond_one_round = (n_envs + epw_f - 1) / epw_f > cus * 4 * FTL_FRAMESG_WPE;
         h->regroup = (off ? off[0] != '1' : (beyond_one_round || cfg->rand_fps_hi > 0)) && (n_envs + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK <= 512;
         h->rg_env = off != nullptr; h->rg_every_env = ev && atoi(ev) > 0; h->rg_slots = cus * 4 * FTL_FRAMESG_WPE; h->rg_epw = epw_f;
@@ -259,20 +288,13 @@ int ftl_create(const ftl_config* cfg, int32_t n_envs, int32_t device, ftl_handle
                            + (size_t)FTL_PAIR_CAP * 2 + 16);  /* candidate list of phase 3 */
     }
     {   // frame kernel LDS: near lists + their counters | frame records (one byte per env and frame) | pending position checks | slot -> env | block boxes
-        const int epw = FTL_WAVE / (P.R <= 4 ? 4 : 8);
         const int f_max = cfg->rand_fps_hi > 0 ? cfg->rand_fps_hi - 1 : cfg->frames_per_step;
         // The searches of frames 1.. wait for the end of the step when the step is short enough for their items to sit in LDS and the frame
         // count is the same for every env; otherwise every frame's searches run right after it (one item per env at most).
         const char* dv = getenv("FTL_DEFER");
         P.fr_defer = (cfg->rand_fps_hi == 0 && f_max >= 2 && f_max <= 16 && cfg->traj_cap <= 65535 && !(dv && dv[0] == '0')) ? 1 : 0;
         if (cfg->traj_cap > 65535 || f_max > 4095) { delete h; return fail(FTL_E_INVALID, "traj_cap above 65535 or more than 4095 frames per step"); }
-        size_t o = align_up((size_t)epw * cfg->n_static * 16 + (size_t)epw * 4 + 32, 16);
-        P.fr_rec_stride = (int)align_up((size_t)f_max, 16);
-        P.fr_rec_off = (int)o; o += (size_t)P.fr_rec_stride * epw;
-        P.fr_pend_off = (int)o; o += (size_t)epw * (P.fr_defer ? f_max - 1 : 1) * 16;
-        P.fr_env_off = (int)o; o += (size_t)epw * 4 + 16 + (size_t)epw * 16;      // slot -> env, item counter, box of the trajectory block being filled
-        P.fr_lds = (int)o;
-        if (o > 64 * 1024) { delete h; return fail(FTL_E_INVALID, "the frame kernel needs more than 64 KiB of LDS per wavefront (static rects x frames per step)"); }
+        if (set_lanes(h)) { delete h; return fail(FTL_E_INVALID, "the frame kernel needs more than 64 KiB of LDS per wavefront (static rects x frames per step)"); }
     }
     auto debug_pad = [](const char* name) { const char* v = getenv(name); const int p = v ? atoi(v) : 0; return p < 0 ? 0 : (p > 48 * 1024 ? 48 * 1024 : p); };
     P.lds_rays += debug_pad("FTL_DEBUG_LDS_PAD_RAYS");      // diagnostic: occupancy of the ray kernel without touching the code
@@ -361,6 +383,8 @@ int ftl_tune(ftl_handle* h, int32_t what, int32_t value) {
     switch (what) {
     case FTL_TUNE_COSCHEDULED_ENVS:
         if (value < h->P.n_envs) return fail(FTL_E_INVALID, "co-scheduled envs below this handle's own");
+        h->co_envs = value;
+        if (set_lanes(h)) return fail(FTL_E_INVALID, "the frame kernel needs more than 64 KiB of LDS per wavefront (static rects x frames per step)");
         if (!h->rg_env)
             h->regroup = ((value + h->rg_epw - 1) / h->rg_epw > h->rg_slots || h->P.cfg.rand_fps_hi > 0) && (h->P.n_envs + FTL_RG_BLOCK - 1) / FTL_RG_BLOCK <= 512;
         return FTL_OK;
@@ -424,17 +448,17 @@ static int launch(ftl_handle* h, const FtlCall& call, void* stream) {
         tev = h->tev.data() + h->tev_used; h->tev_used += 5;
     }
     auto launch_range = [&](int part, int parts, hipStream_t s) {
-        const int epw0 = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
+        const int epw0 = FTL_WAVE / h->G;
         const int n_groups = (h->P.n_envs + epw0 - 1) / epw0;
         const int my_groups = (n_groups - part + parts - 1) / parts;
         FtlCall c2 = call; c2.part = part; c2.parts = parts; c2.epw = epw0;
         const int count = my_groups * epw0;              // slots of this launch (the tail of the last group may be idle)
         const bool reg = h->P.cfg.n_speed_regime >= 0 || h->P.cfg.n_acc_regime >= 0 || h->P.cfg.rand_fps_hi > 0;
-        const int epw = FTL_WAVE / (h->P.R <= 4 ? 4 : 8);
+        const int epw = FTL_WAVE / h->G;
         size_t lds = (size_t)h->P.fr_lds + h->lds_pad;
         const dim3 grid((count + epw - 1) / epw), block(FTL_WAVE);
         if (tev) (void)hipEventRecord(tev[0], s);
-        if (h->P.R <= 4) {
+        if (h->G == 4) {
             if (reg) hipLaunchKernelGGL((ftl_frames_group_kernel<4, true>), grid, block, lds, s, h->dP, c2);
             else hipLaunchKernelGGL((ftl_frames_group_kernel<4, false>), grid, block, lds, s, h->dP, c2);
         } else {

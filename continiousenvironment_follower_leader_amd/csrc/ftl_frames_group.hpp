@@ -19,7 +19,13 @@ namespace ftl {
 template <int G, int K>
 __device__ __forceinline__ int gb_i(int v) {
     if constexpr (G == 4) return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, false);    // quad_perm:[K,K,K,K]
-    else return __shfl(v, (threadIdx.x & ~(G - 1)) + K);
+    else if constexpr (G == 8) {
+        // a group of 8 = two quads of one DPP row: every quad broadcasts its own lane K & 3, then the quad that does not hold lane K takes
+        // the other quad's copy (row_shr:4 into banks 1 and 3, or row_shl:4 into banks 0 and 2) -- two DPP moves, no trip through the LDS unit
+        const int t = __builtin_amdgcn_mov_dpp(v, (K & 3) * 0x55, 0xf, 0xf, false);
+        if constexpr (K < 4) return __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xA, false);
+        else return __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0x5, false);
+    } else return __shfl(v, (threadIdx.x & ~(G - 1)) + K);
 }
 template <int G, int K> __device__ __forceinline__ float gb_f(float v) { return __int_as_float(gb_i<G, K>(__float_as_int(v))); }
 template <int G, int K> __device__ __forceinline__ double gb_d(double v) {
@@ -30,6 +36,10 @@ template <int G, int K> __device__ __forceinline__ double gb_d(double v) {
 __device__ __forceinline__ int gx_i(int v, int off, int G) {
     if (off == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);      // quad_perm:[1,0,3,2]
     if (off == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);      // quad_perm:[2,3,0,1]
+    if (off == 4) {                                                               // the two quads of a group of 8 swap: row_shr:4 / row_shl:4
+        const int t = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xA, false);     // banks 1, 3 <- banks 0, 2
+        return __builtin_amdgcn_update_dpp(t, v, 0x104, 0xf, 0x5, false);            // banks 0, 2 <- banks 1, 3 (of the original)
+    }
     return __shfl_xor(v, off, G);
 }
 __device__ __forceinline__ float gx_f(float v, int off, int G) { return __int_as_float(gx_i(__float_as_int(v), off, G)); }
@@ -43,6 +53,11 @@ template <int G> __device__ __forceinline__ double g_up_d(double v, int off) {
         const int hi = __double2hiint(v), lo = __double2loint(v);
         if (off == 1) return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x90, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x90, 0xf, 0xf, false));   // quad_perm:[0,0,1,2]
         return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x44, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x44, 0xf, 0xf, false));                  // quad_perm:[0,1,0,1]
+    } else if constexpr (G == 8) {        // row_shr inside the DPP row (lanes r < off of a group get a neighbour group's value: "whatever", as documented)
+        const int hi = __double2hiint(v), lo = __double2loint(v);
+        if (off == 1) return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x111, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x111, 0xf, 0xf, false));
+        if (off == 2) return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x112, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x112, 0xf, 0xf, false));
+        return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x114, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x114, 0xf, 0xf, false));
     } else return __shfl_up(v, off, G);
 }
 // value of lane k (group-uniform, run-time) of the group

@@ -18,7 +18,7 @@ T = (C.c_ulonglong * (2 * 8192))(); I = (C.c_uint * 8192)()
 for rep in range(3):
     env.step(acts[rep], auto_reset=True)
     env.lib.ftl_debug_wave_timeline(T, I)
-    nw = (n + 15) // 16 if cfg.n_robots <= 4 else (n + 7) // 8
+    nw = (n + 15) // 16 if (cfg.n_robots <= 4 and n > 8192) else (n + 7) // 8      # (small batches run 8 envs per wavefront)
     t = np.array(list(T), dtype=np.int64).reshape(8192, 2)[:nw]; info = np.array(list(I), dtype=np.int64)[:nw]
     t0 = t[:, 0].min(); st = (t[:, 0] - t0) / 100.0; en = (t[:, 1] - t0) / 100.0; d = en - st
     rs = (info & 1) == 1; ns = (info >> 8) & 255; nw = (info >> 16) & 255; nf = (info >> 24) & 255

@@ -13,6 +13,16 @@ from golden_util import GOLDEN, close, config_for, episode_names, load_episode, 
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["4 lanes per env", "8 lanes per env"])
+def lanes_per_env(request, monkeypatch):
+    """The frame kernel runs an env on 4 lanes of a wavefront (16 envs per wavefront; the large batches) or on 8 (8 envs per wavefront:
+    configs with more than two dynamic obstacles, and every config on a batch small enough for each wavefront to have a SIMD of its own --
+    which is every batch of this file).  Everything here runs in both forms (FTL_DEBUG_G8 at ftl_create; configs that need 8 lanes take
+    them either way)."""
+    monkeypatch.setenv("FTL_DEBUG_G8", "0" if request.param.startswith("4") else "1")
+
+
+
 def _vec(cfg, n, scen_list):
     from continiousenvironment_follower_leader_amd.vec_game import ScenarioPool, VecGame
     env = VecGame(n, device="cuda:0", config=cfg)
