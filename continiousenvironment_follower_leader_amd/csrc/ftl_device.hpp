@@ -514,6 +514,13 @@ __global__ void __launch_bounds__(FTL_WAVE, FTL_RAYS_WPE) ftl_rays_kernel(const 
 
 #pragma nounroll
     for (int which = 0; which < 2; which++) {
+        // The lane index is made opaque once per pass (it shadows the kernel's `lane` from here on): left visible, every per-lane address of
+        // the pass -- LDS slots, the lane's rects -- is formed once before this loop and kept alive across it, and at the 80 registers that
+        // six wavefronts per SIMD allow the compiler paid for that with a register pair in scratch (512 B of scratch writes per env-step in
+        // the PMC write counter, and a reload in the middle of the pass).
+        int lane_v = (int)threadIdx.x;
+        asm volatile("" : "+v"(lane_v));
+        const int lane = lane_v;
         int n_sens = 0; float lmax = 0.0f;
         FTL_FOR_LASERS(k) if (c.lasers[k].after_tracker == which) { n_sens++; lmax = fmaxf(lmax, (float)c.lasers[k].length); }
         if (n_sens == 0) continue;

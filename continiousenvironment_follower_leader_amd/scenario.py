@@ -96,7 +96,10 @@ class ScenarioRing:
         self.cfg, self.half, self.device = cfg, int(half), device
         self.pool = ScenarioPool.empty(cfg, 2 * self.half, device)
         self._seeds = iter(seeds)
-        self._chunk = chunk or max(256, self.half // 4)
+        # one generator call per half as a rule (87 % of the seeds give a usable world): between calls the thread needs the interpreter lock,
+        # which the thread that launches the steps gives up a few hundred times a second only
+        self._chunk = chunk or max(256, int(self.half * 1.25) + 16)
+        self._free = []               # pinned host buffer sets whose copy has landed (reused: pinning 80 MB holds the interpreter lock for tens of ms)
         self._n_threads = n_threads
         self._take = itertools.islice
         c = cfg.c
@@ -133,7 +136,15 @@ class ScenarioRing:
             keep = np.nonzero(g["usable"])[0][:self.half - have]
             parts.append({k: g[k][keep] for k in keys})
             have += len(keep)
-        host = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([p[k] for p in parts]))).pin_memory() for k in keys}
+        with self._lock:
+            host = self._free.pop() if self._free else None
+        if host is None:
+            host = {k: torch.empty((self.half,) + parts[0][k].shape[1:], dtype=torch.from_numpy(parts[0][k][:0]).dtype).pin_memory() for k in keys}
+        for k in keys:                     # (large same-dtype copies: numpy releases the interpreter lock while they run)
+            dst, at = host[k].numpy(), 0
+            for p in parts:
+                dst[at:at + len(p[k])] = p[k]
+                at += len(p[k])
         self.generated += self.half
         return host
 
@@ -188,6 +199,9 @@ class ScenarioRing:
             with self._lock:
                 host, self._ready = self._ready, None
             if host is not None:
+                if self.history is None and getattr(self, "_held", None) is not None:
+                    with self._lock:
+                        self._free.append(self._held)      # its copy landed a window move ago
                 self._held = host        # keep the pinned buffers alive until the copy has landed
                 # `step` counts the steps the HOST has queued; the device may be many steps behind.  The copy must not overtake them:
                 # the side stream waits for everything queued on the batch's stream so far (steps that may still read this half).
