@@ -33,7 +33,7 @@
                                              // chunk at most.  Kept small on purpose: 512 bytes of LDS more cost the ray kernel a wavefront per CU
                                              // and 6 % of its speed (FTL_DEBUG_LDS_PAD_RAYS)
 #ifndef FTL_RAYS_WPE
-#define FTL_RAYS_WPE 6      // 80 VGPRs (one spilled in the headline instantiation); 24 wavefronts per CU need <= 6.8 KB of LDS per env
+#define FTL_RAYS_WPE 6      // 80 VGPRs (none spilled in the one-stream instantiations); 24 wavefronts per CU need <= 6.8 KB of LDS per env
 #endif
 
 // per-sensor record of the ray kernel's phase 3 (built on the host in ftl_create)
