@@ -207,6 +207,28 @@ def test_pipelined_parts_are_bit_identical_to_one_batch(parts, sorted_envs, monk
     a.close(); b.close()
 
 
+def test_pipelined_batch_fills_the_fused_policy_tensor():
+    """The fused ContinuousObserveModifier_sensorPrev output (row f1) of a pipelined batch: one [n, H, W] tensor that the parts fill by row
+    range, equal to the one-batch tensor."""
+    from continiousenvironment_follower_leader_amd.vec_game import PipelinedVecGame, ScenarioPool, VecGame
+    n = 300
+    cfg = _pool_cfg(max_steps=200, warm_start=10)
+    pool = ScenarioPool.from_npz(cfg, GOLDEN + "/pool_B.npz", "cuda:0")
+    a = VecGame(n, device="cuda:0", config=cfg, policy_obs=True); a.load_scenarios(pool)
+    b = PipelinedVecGame(n, parts=2, device="cuda:0", config=cfg, policy_obs=True); b.load_scenarios(pool)
+    assert b.policy_obs is not None and b.policy_obs.shape == a.policy_obs.shape
+    idx = torch.arange(n, dtype=torch.int32) % pool.n
+    a.reset(idx); b.reset(idx)
+    for t in range(25):
+        act = _actions(cfg, n, 40 + t)
+        a.step(act, auto_reset=True); b.step(act, auto_reset=True)
+    b.join(); torch.cuda.synchronize()
+    assert torch.equal(a.policy_obs, b.policy_obs)
+    assert float(a.policy_obs.abs().sum()) > 0
+    b.raise_on_errors()
+    a.close(); b.close()
+
+
 def test_auto_reset_equals_explicit_reset():
     """An env that finishes under FTL_STEP_AUTO_RESET must continue exactly like a fresh env reset to the next scenario."""
     n = 96
